@@ -1,0 +1,139 @@
+/*
+ * higsfa.h — C ABI of the MI355X-native HiGSFA inference path.
+ *
+ * Drop-in boundary for PyFaceAnalysis' hot call
+ *
+ *     sl = networks[num_network].execute(subimages_arr, benchmark=benchmark)
+ *                                      (reference: FaceDetectUpdated.py:699;
+ *                                       also face_analysis.py:1064 and :1257)
+ *
+ * The reference has no native code and no FFI; these entry points are what a
+ * ctypes/cffi binding for that one call needs: load a flow description, run batches of
+ * flattened sub-images through it on one GPU, read results and per-stage timings back.
+ * Plain C types only.  All functions return 0 (HG_OK) on success or a negative hg_status;
+ * hg_last_error() returns a thread-local message for the last failure on the calling thread.
+ *
+ * Threading: one hg_flow may be used by one thread at a time; different flows are
+ * independent.  The library keeps no global mutable state besides the last-error string.
+ * There is NO CPU execution path: without a usable HIP device hg_flow_to_device /
+ * hg_flow_execute* fail with HG_ERR_DEVICE.
+ */
+#ifndef HIGSFA_H
+#define HIGSFA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HG_VERSION 100 /* 0.1.0 */
+
+typedef struct hg_flow hg_flow;
+
+/* Element types accepted for the sub-image matrix / produced for the feature matrix.
+ * The reference passes float64 arrays holding integer pixel values 0..255
+ * (images_asarray, face_analysis.py:786) and receives float64 (MDP node dtype). */
+enum hg_dtype { HG_U8 = 0, HG_F32 = 1, HG_F64 = 2 };
+
+enum hg_status {
+    HG_OK = 0,
+    HG_ERR_ARG = -1,      /* null pointer, bad dtype, bad leading dimension, ...            */
+    HG_ERR_FORMAT = -2,   /* malformed / truncated / unsupported blob                        */
+    HG_ERR_DIM = -3,      /* input_dim / output_dim mismatch (MDP raises on these too)        */
+    HG_ERR_DEVICE = -4,   /* no HIP device, HIP call failed, flow not on a device             */
+    HG_ERR_NOMEM = -5,
+    HG_ERR_STATE = -6     /* call made in the wrong state (e.g. timings without profiling)    */
+};
+
+/* Which execution plan the loader chose for a flow. */
+enum hg_plan_kind {
+    HG_PLAN_GENERIC = 0,  /* step-by-step kernels on row-major activations (any flow)         */
+    HG_PLAN_FUSED = 1     /* per-layer fused gather+affine+expansion+affine MFMA kernels       */
+};
+
+typedef struct hg_info {
+    int64_t input_dim;        /* columns of x  (mdp Flow: flow[0].input_dim)                   */
+    int64_t output_dim;       /* columns of y  (flow[-1].output_dim)                           */
+    int32_t n_top_nodes;      /* len(flow) — top-level nodes as the reference's flow has them  */
+    int32_t plan_kind;        /* enum hg_plan_kind                                             */
+    int32_t n_stages;         /* kernels (fused) or steps (generic) launched per execute       */
+    int32_t device;           /* HIP device ordinal, -1 while host-only                        */
+    int64_t weight_bytes;     /* device bytes held by weights/descriptors                      */
+    int64_t flops_per_row;    /* algorithmic FLOPs per sub-image: sum 2*in*out over affines    */
+    int64_t padded_flops_per_row; /* FLOPs the fused MFMA tiling actually issues per row       */
+    int64_t workspace_bytes;  /* device bytes currently reserved for activations              */
+} hg_info;
+
+int hg_version(void);
+const char* hg_last_error(void);
+
+/* Number of visible HIP devices (0 and HG_OK when there are none / no driver). */
+int hg_device_count(int* count);
+
+/* Parse a flow blob ("HGSFAFL1", see pyfaceanalysis_amd/blob.py) and build the execution
+ * plan on the host.  Replaces: cache_obj.load_obj_from_cache (pickle) in
+ * face_analysis.py:457.  Touches no GPU.  `flags`: bit0 = force the generic plan. */
+int hg_flow_load(const void* blob, size_t nbytes, int flags, hg_flow** out);
+void hg_flow_free(hg_flow* f);
+
+int hg_flow_info(const hg_flow* f, hg_info* info);
+
+/* Human-readable plan listing (counterpart of more_nodes.describe_flow,
+ * FaceDetectUpdated.py:193).  Writes at most cap-1 chars + NUL; returns needed length in
+ * *needed when non-null. */
+int hg_flow_describe(const hg_flow* f, char* buf, size_t cap, size_t* needed);
+
+/* Upload weights/descriptors to HIP device `device` (one device per flow handle). */
+int hg_flow_to_device(hg_flow* f, int device);
+
+/* Pre-size the activation workspace for batches of up to `max_rows` rows so that
+ * hg_flow_execute_device performs no allocation. */
+int hg_flow_reserve(hg_flow* f, int64_t max_rows);
+
+/* y[n, 0:y_cols] = flow(x[n, :]) with HOST buffers (the ndarray-in / ndarray-out call of
+ * FaceDetectUpdated.py:699).  x: n rows of input_dim elements, row stride ldx elements;
+ * y: n rows, the first y_cols (<= output_dim) columns, row stride ldy elements.  The caller
+ * usually wants only the first classifier.input_dim columns (FaceDetectUpdated.py:709,719).
+ * n == 0 is valid and a no-op (reference guards len(subimages_arr) > 0 at :694).
+ * Synchronous: returns after y is complete. */
+int hg_flow_execute(hg_flow* f, const void* x, int x_dtype, int64_t n, int64_t ldx,
+                    void* y, int y_dtype, int64_t y_cols, int64_t ldy);
+
+/* Same with DEVICE buffers on the flow's device, enqueued on `stream` (hipStream_t, may be
+ * null = default stream); returns without synchronising. */
+int hg_flow_execute_device(hg_flow* f, const void* x_dev, int x_dtype, int64_t n, int64_t ldx,
+                           void* y_dev, int y_dtype, int64_t y_cols, int64_t ldy, void* stream);
+
+/* Per-stage timing (the `benchmark=` kwarg of the reference call; benchmarking.py:39-58).
+ * When enabled every stage launch is bracketed by hipEvents on the execution stream. */
+int hg_flow_set_profiling(hg_flow* f, int enabled);
+/* After a profiled execute has completed: accumulated ms and launch count per stage since
+ * the last reset; `cap` entries at most; *n_stages receives the stage count. */
+int hg_flow_stage_times(hg_flow* f, double* total_ms, int64_t* launches, int cap, int* n_stages);
+int hg_flow_stage_name(const hg_flow* f, int stage, char* buf, size_t cap);
+int hg_flow_reset_profile(hg_flow* f);
+
+/* --- Gaussian-classifier soft-label regression -------------------------
+ * The step right after the hot call: classifiers[k].regression(sl[:, 0:d], avg_labels)
+ * (FaceDetectUpdated.py:709-719).  Parameters as stored in the SavedClassifiers pickles:
+ * means (K,d), inv_covs (K,d,d), sqrt_det_covs (K), priors p (K), avg_labels (K); float64.
+ * out_reg[n] = sum_c post_c(x_n) avg_labels[c]; out_std (optional) the posterior std. */
+typedef struct hg_gauss hg_gauss;
+int hg_gauss_create(int32_t n_classes, int32_t dim, const double* means, const double* inv_covs,
+                    const double* sqrt_det_covs, const double* priors, const double* avg_labels,
+                    int device, hg_gauss** out);
+void hg_gauss_free(hg_gauss* g);
+/* x_dev: (n, >=dim) device matrix of dtype x_dtype (F32/F64), row stride ldx; outputs are
+ * device float64 arrays of n elements (out_std may be null).  Enqueued on `stream`. */
+int hg_gauss_regression_device(hg_gauss* g, const void* x_dev, int x_dtype, int64_t n, int64_t ldx,
+                               double* out_reg_dev, double* out_std_dev, void* stream);
+/* Host-buffer convenience wrapper (synchronous). */
+int hg_gauss_regression(hg_gauss* g, const void* x, int x_dtype, int64_t n, int64_t ldx,
+                        double* out_reg, double* out_std);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIGSFA_H */

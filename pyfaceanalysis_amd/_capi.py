@@ -1,0 +1,103 @@
+"""ctypes binding of include/higsfa.h (the drop-in boundary).  No fallback: if the native
+library is missing this module raises at first use."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HG_U8, HG_F32, HG_F64 = 0, 1, 2
+HG_OK = 0
+HG_ERR_ARG, HG_ERR_FORMAT, HG_ERR_DIM, HG_ERR_DEVICE, HG_ERR_NOMEM, HG_ERR_STATE = -1, -2, -3, -4, -5, -6
+HG_PLAN_GENERIC, HG_PLAN_FUSED = 0, 1
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libhigsfa.so")
+_lib = None
+
+
+class HgInfo(C.Structure):
+    _fields_ = [("input_dim", C.c_int64), ("output_dim", C.c_int64), ("n_top_nodes", C.c_int32),
+                ("plan_kind", C.c_int32), ("n_stages", C.c_int32), ("device", C.c_int32),
+                ("weight_bytes", C.c_int64), ("flops_per_row", C.c_int64),
+                ("padded_flops_per_row", C.c_int64), ("workspace_bytes", C.c_int64)]
+
+
+class NativeLibraryMissing(ImportError):
+    pass
+
+
+def lib():
+    """Load libhigsfa.so (built by ``python -m pyfaceanalysis_amd.build``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise NativeLibraryMissing(
+            "%s not found: the HIP library is the only execution path of this package; build it "
+            "with `python -m pyfaceanalysis_amd.build` (or __graft_entry__.build())" % _LIB_PATH)
+    L = C.CDLL(_LIB_PATH)
+    vp, i64, i32, sz = C.c_void_p, C.c_int64, C.c_int, C.c_size_t
+    sigs = {
+        "hg_version": (C.c_int, []),
+        "hg_last_error": (C.c_char_p, []),
+        "hg_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+        "hg_flow_load": (C.c_int, [vp, sz, i32, C.POINTER(vp)]),
+        "hg_flow_free": (None, [vp]),
+        "hg_flow_info": (C.c_int, [vp, C.POINTER(HgInfo)]),
+        "hg_flow_describe": (C.c_int, [vp, C.c_char_p, sz, C.POINTER(sz)]),
+        "hg_flow_to_device": (C.c_int, [vp, i32]),
+        "hg_flow_reserve": (C.c_int, [vp, i64]),
+        "hg_flow_execute": (C.c_int, [vp, vp, i32, i64, i64, vp, i32, i64, i64]),
+        "hg_flow_execute_device": (C.c_int, [vp, vp, i32, i64, i64, vp, i32, i64, i64, vp]),
+        "hg_flow_set_profiling": (C.c_int, [vp, i32]),
+        "hg_flow_stage_times": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(i64), i32, C.POINTER(i32)]),
+        "hg_flow_stage_name": (C.c_int, [vp, i32, C.c_char_p, sz]),
+        "hg_flow_reset_profile": (C.c_int, [vp]),
+        "hg_gauss_create": (C.c_int, [C.c_int32, C.c_int32, vp, vp, vp, vp, vp, i32, C.POINTER(vp)]),
+        "hg_gauss_free": (None, [vp]),
+        "hg_gauss_regression_device": (C.c_int, [vp, vp, i32, i64, i64, vp, vp, vp]),
+        "hg_gauss_regression": (C.c_int, [vp, vp, i32, i64, i64, vp, vp]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+EXPORTED_SYMBOLS = (
+    "hg_version", "hg_last_error", "hg_device_count", "hg_flow_load", "hg_flow_free", "hg_flow_info",
+    "hg_flow_describe", "hg_flow_to_device", "hg_flow_reserve", "hg_flow_execute",
+    "hg_flow_execute_device", "hg_flow_set_profiling", "hg_flow_stage_times", "hg_flow_stage_name",
+    "hg_flow_reset_profile", "hg_gauss_create", "hg_gauss_free", "hg_gauss_regression_device",
+    "hg_gauss_regression",
+)
+
+_EXC = {HG_ERR_ARG: ValueError, HG_ERR_FORMAT: ValueError, HG_ERR_DIM: ValueError,
+        HG_ERR_DEVICE: RuntimeError, HG_ERR_NOMEM: MemoryError, HG_ERR_STATE: RuntimeError}
+
+
+class NodeException(ValueError):
+    """Counterpart of mdp.NodeException (dimension mismatches raise this in MDP)."""
+
+
+def check(rc):
+    if rc == HG_OK:
+        return
+    msg = lib().hg_last_error().decode("utf-8", "replace")
+    if rc == HG_ERR_DIM:
+        raise NodeException(msg)
+    raise _EXC.get(rc, RuntimeError)("higsfa: " + msg)
+
+
+def np_dtype_code(dt):
+    dt = np.dtype(dt)
+    if dt == np.uint8:
+        return HG_U8
+    if dt == np.float32:
+        return HG_F32
+    if dt == np.float64:
+        return HG_F64
+    return None

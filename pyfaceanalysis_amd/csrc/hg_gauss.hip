@@ -1,0 +1,195 @@
+// Gaussian-classifier soft-label regression: the step right after the hot call,
+//   reg_out = classifiers[k].regression(sl[:, 0:reg_num_signals], avg_labels)
+// (FaceDetectUpdated.py:709-719; face_analysis.py:1068-1073, 1261-1290).  Parameters are the
+// attributes stored in SavedClassifiers/*.pckl (means, inv_covs, _sqrt_def_covs, p, avg_labels).
+//
+//   post_c(x) ∝ p_c / sqrtdet_c * exp(-1/2 (x-m_c)' S_c^-1 (x-m_c)),  normalised over classes
+//   reg(x)    = sum_c post_c(x) avg_labels[c]
+//   std(x)    = sqrt(sum_c post_c(x) (avg_labels[c] - reg)^2)
+// Evaluated in the log domain in fp64 (sqrtdet reaches 1e42 in the shipped classifiers).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+#include "hg_common.hpp"
+
+struct hg_gauss {
+    int K = 0, d = 0, device = -1;
+    hg::DevBuf means, inv_covs, logw, avg;  // logw[c] = log p_c - log sqrtdet_c
+    hg::DevBuf sx, sreg, sstd;              // host-call staging
+};
+
+namespace {
+
+thread_local std::string g_gauss_error;
+
+constexpr int kMaxClasses = 1024;
+
+template <typename T>
+__global__ void __launch_bounds__(64)
+k_gauss_regression(const T* __restrict__ x, int64_t ldx, int64_t n, int K, int d, const double* __restrict__ means,
+                   const double* __restrict__ inv_covs, const double* __restrict__ logw, const double* __restrict__ avg,
+                   double* __restrict__ out_reg, double* __restrict__ out_std) {
+    // one 64-lane wave per row; lane c handles classes c, c+64, ...
+    __shared__ double xs[64];
+    const int64_t row = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (lane < d) xs[lane] = (double)x[row * ldx + lane];
+    __syncthreads();
+    double lmax = -INFINITY;
+    // pass 1: log-weights, kept in registers for up to 16 classes per lane
+    double lp[kMaxClasses / 64];
+#pragma unroll
+    for (int s = 0; s < kMaxClasses / 64; ++s) {
+        int c = lane + 64 * s;
+        double v = -INFINITY;
+        if (c < K) {
+            const double* m = means + (size_t)c * d;
+            const double* S = inv_covs + (size_t)c * d * d;
+            double q = 0;
+            for (int i = 0; i < d; ++i) {
+                double t = 0;
+                for (int j = 0; j < d; ++j) t += S[i * d + j] * (xs[j] - m[j]);
+                q += t * (xs[i] - m[i]);
+            }
+            v = logw[c] - 0.5 * q;
+        }
+        lp[s] = v;
+        lmax = fmax(lmax, v);
+    }
+    for (int o = 32; o > 0; o >>= 1) lmax = fmax(lmax, __shfl_xor(lmax, o));
+    double sw = 0, swa = 0, swa2 = 0;
+#pragma unroll
+    for (int s = 0; s < kMaxClasses / 64; ++s) {
+        int c = lane + 64 * s;
+        if (c < K) {
+            double w = exp(lp[s] - lmax), a = avg[c];
+            sw += w;
+            swa += w * a;
+            swa2 += w * a * a;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        sw += __shfl_xor(sw, o);
+        swa += __shfl_xor(swa, o);
+        swa2 += __shfl_xor(swa2, o);
+    }
+    if (lane == 0) {
+        double reg = swa / sw;
+        out_reg[row] = reg;
+        if (out_std) out_std[row] = sqrt(fmax(swa2 / sw - reg * reg, 0.0));
+    }
+}
+
+template <typename F>
+int guarded(F&& fn) {
+    try {
+        fn();
+        return HG_OK;
+    } catch (const hg::Error& e) {
+        g_gauss_error = e.what();
+        return e.code;
+    } catch (const std::exception& e) {
+        g_gauss_error = e.what();
+        return HG_ERR_STATE;
+    }
+}
+
+void launch(hg_gauss* g, const void* x, int x_dtype, int64_t n, int64_t ldx, double* reg, double* sd, hipStream_t st) {
+    if (n == 0) return;
+    if (n > 0x7fffffffll) hg::fail(HG_ERR_ARG, "too many rows");
+    if (x_dtype == HG_F32)
+        hipLaunchKernelGGL(k_gauss_regression<float>, (unsigned)n, 64, 0, st, (const float*)x, ldx, n, g->K, g->d,
+                           (const double*)g->means.p, (const double*)g->inv_covs.p, (const double*)g->logw.p,
+                           (const double*)g->avg.p, reg, sd);
+    else if (x_dtype == HG_F64)
+        hipLaunchKernelGGL(k_gauss_regression<double>, (unsigned)n, 64, 0, st, (const double*)x, ldx, n, g->K, g->d,
+                           (const double*)g->means.p, (const double*)g->inv_covs.p, (const double*)g->logw.p,
+                           (const double*)g->avg.p, reg, sd);
+    else
+        hg::fail(HG_ERR_ARG, "feature dtype must be HG_F32 or HG_F64");
+    HG_HIP(hipGetLastError());
+}
+
+}  // namespace
+
+// hg_last_error() lives in hg_capi.cpp; route gauss errors through the same accessor.
+extern "C" const char* hg_last_error(void);
+namespace hg { void set_last_error(const std::string& s); }
+
+extern "C" {
+
+int hg_gauss_create(int32_t n_classes, int32_t dim, const double* means, const double* inv_covs, const double* sqrt_det_covs,
+                    const double* priors, const double* avg_labels, int device, hg_gauss** out) {
+    int rc = guarded([&] {
+        if (!out) hg::fail(HG_ERR_ARG, "null output handle pointer");
+        *out = nullptr;
+        if (!means || !inv_covs || !sqrt_det_covs || !priors || !avg_labels) hg::fail(HG_ERR_ARG, "null parameter array");
+        if (n_classes < 1 || n_classes > kMaxClasses) hg::fail(HG_ERR_ARG, "n_classes must be 1..%d", kMaxClasses);
+        if (dim < 1 || dim > 64) hg::fail(HG_ERR_ARG, "dim must be 1..64");
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+            hg::fail(HG_ERR_DEVICE, "no HIP device available (this library has no CPU execution path)");
+        if (device < 0 || device >= count) hg::fail(HG_ERR_DEVICE, "device %d out of range", device);
+        HG_HIP(hipSetDevice(device));
+        auto g = std::make_unique<hg_gauss>();
+        g->K = n_classes;
+        g->d = dim;
+        g->device = device;
+        std::vector<double> lw(n_classes);
+        for (int c = 0; c < n_classes; ++c) {
+            if (!(sqrt_det_covs[c] > 0) || !(priors[c] >= 0)) hg::fail(HG_ERR_ARG, "class %d: non-positive sqrt-det or negative prior", c);
+            lw[c] = std::log(priors[c]) - std::log(sqrt_det_covs[c]);
+        }
+        g->means.upload(means, sizeof(double) * n_classes * dim);
+        g->inv_covs.upload(inv_covs, sizeof(double) * n_classes * dim * dim);
+        g->logw.upload(lw.data(), sizeof(double) * n_classes);
+        g->avg.upload(avg_labels, sizeof(double) * n_classes);
+        *out = g.release();
+    });
+    if (rc != HG_OK) hg::set_last_error(g_gauss_error);
+    return rc;
+}
+
+void hg_gauss_free(hg_gauss* g) {
+    if (g && g->device >= 0) (void)hipSetDevice(g->device);
+    delete g;
+}
+
+int hg_gauss_regression_device(hg_gauss* g, const void* x, int x_dtype, int64_t n, int64_t ldx, double* out_reg,
+                               double* out_std, void* stream) {
+    int rc = guarded([&] {
+        if (!g) hg::fail(HG_ERR_ARG, "null classifier handle");
+        if (n < 0) hg::fail(HG_ERR_ARG, "negative row count");
+        if (ldx < g->d) hg::fail(HG_ERR_DIM, "x has %lld columns but the classifier's input_dim is %d", (long long)ldx, g->d);
+        if (n > 0 && (!x || !out_reg)) hg::fail(HG_ERR_ARG, "null data pointer");
+        HG_HIP(hipSetDevice(g->device));
+        launch(g, x, x_dtype, n, ldx, out_reg, out_std, (hipStream_t)stream);
+    });
+    if (rc != HG_OK) hg::set_last_error(g_gauss_error);
+    return rc;
+}
+
+int hg_gauss_regression(hg_gauss* g, const void* x, int x_dtype, int64_t n, int64_t ldx, double* out_reg, double* out_std) {
+    int rc = guarded([&] {
+        if (!g) hg::fail(HG_ERR_ARG, "null classifier handle");
+        if (n < 0) hg::fail(HG_ERR_ARG, "negative row count");
+        if (ldx < g->d) hg::fail(HG_ERR_DIM, "x has %lld columns but the classifier's input_dim is %d", (long long)ldx, g->d);
+        if (n == 0) return;
+        if (!x || !out_reg) hg::fail(HG_ERR_ARG, "null data pointer");
+        if (x_dtype != HG_F32 && x_dtype != HG_F64) hg::fail(HG_ERR_ARG, "feature dtype must be HG_F32 or HG_F64");
+        HG_HIP(hipSetDevice(g->device));
+        const size_t es = hg::dtype_size(x_dtype);
+        g->sx.alloc((size_t)n * g->d * es);
+        g->sreg.alloc((size_t)n * 8);
+        if (out_std) g->sstd.alloc((size_t)n * 8);
+        HG_HIP(hipMemcpy2D(g->sx.p, g->d * es, x, (size_t)ldx * es, g->d * es, (size_t)n, hipMemcpyHostToDevice));
+        launch(g, g->sx.p, x_dtype, n, g->d, (double*)g->sreg.p, out_std ? (double*)g->sstd.p : nullptr, nullptr);
+        HG_HIP(hipMemcpy(out_reg, g->sreg.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+        if (out_std) HG_HIP(hipMemcpy(out_std, g->sstd.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+    });
+    if (rc != HG_OK) hg::set_last_error(g_gauss_error);
+    return rc;
+}
+
+}  // extern "C"
