@@ -1,0 +1,219 @@
+#!/usr/bin/env python
+"""Headline benchmark: 128x128 sub-images/s through the 11-layer HiGSFA net (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path (flow.execute on a device-resident batch) over
+ROWS_PER_GPU synthetic 128x128 sub-images per GPU (BASELINE.json configs[1]: 4096 on one GPU;
+configs[3]: 32768 sharded over 8 GPUs = 4096 per GPU, i.e. weak scaling), fp32, network
+"U11L-128"  with trained random-init weights.  Inputs are resident in HBM before
+the timed region; for N > 1 every step ends with the RCCL all-gather of the first 20 slow
+features (north_star).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ROWS_PER_GPU = 4096
+N_COLS = 20                      # first 20 slow features are what callers consume
+SIDE = 128
+PRESET = "U11L-128"
+PEAK_MFMA_F32_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(nodes, n=256, reps=6):
+    """MDP-structured numpy float64 restatement (oracle/) timed on this box's host cores.
+    Bounded sample: `reps` passes over n sub-images after one warm-up; best pass reported."""
+    from oracle import mdp_restate
+    from pyfaceanalysis_amd import synth
+    x = synth.make_subimages(n, SIDE, dtype=np.float64)
+    mdp_restate.execute_flow(nodes, x)
+    best = 1e30
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        mdp_restate.execute_flow(nodes, x)
+        best = min(best, time.perf_counter() - t0)
+    threads = os.cpu_count() or 1
+    try:
+        from threadpoolctl import threadpool_info
+        blas = [p["num_threads"] for p in threadpool_info() if p.get("user_api") == "blas"]
+        if blas:
+            threads = max(blas)
+    except Exception:
+        pass
+    return {"value": n / best, "unit": "sub-images/s", "cores": threads, "kind": "port",
+            "sample": "%d sub-images of 128x128 float64 through oracle/mdp_restate.py (MDP-structured numpy "
+                      "restatement: per-node Python loop + numpy.dot), best of %d passes after 1 warm-up; "
+                      "numpy BLAS threads=%d" % (n, reps, threads)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=ROWS_PER_GPU, help="sub-images per GPU per step")
+    ap.add_argument("--input-dtype", default="float32", choices=["float32", "uint8", "float64"])
+    ap.add_argument("--generic", action="store_true", help="force the generic plan (diagnostic)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from __graft_entry__ import build
+    from pyfaceanalysis_amd import synth
+    from pyfaceanalysis_amd.flow import Flow
+    from pyfaceanalysis_amd.sharded import gather_features
+
+    # --- model: rank 0 builds (and caches) the net, the others load the cached blob
+    if rank == 0:
+        build()
+        blob, nodes = synth.cached_preset_blob(PRESET)
+    if world > 1:
+        dist.barrier()
+    if rank != 0:
+        blob, nodes = synth.cached_preset_blob(PRESET)
+    flow = Flow.from_blob(blob, device=local_rank, output_dtype=np.float32, force_generic=args.generic)
+    info = flow.info()
+    rows = args.rows
+    flow.reserve(rows)
+
+    # --- data: this rank's shard of the global batch, resident in HBM
+    in_dt = np.dtype(args.input_dtype)
+    x_host = synth.make_subimages(rows, SIDE, seed=synth.INPUT_SEED + rank, dtype=in_dt)
+    x = torch.from_numpy(x_host).to(dev)
+    y = torch.empty((rows, N_COLS), dtype=torch.float32, device=dev)
+    y_all = torch.empty((rows * world, N_COLS), dtype=torch.float32, device=dev) if world > 1 else None
+    stream = torch.cuda.current_stream(dev)
+
+    def step(profile=False):
+        flow.execute_device(x.data_ptr(), in_dt, rows, x.shape[1], y.data_ptr(), np.float32, N_COLS, N_COLS,
+                            stream=stream.cuda_stream, profile=profile)
+        if world > 1:
+            gather_features(y, y_all)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # --- per-kernel durations: HIP events recorded by the library around every stage launch, on
+    # the stream the kernels run on (separate passes, outside the timed region)
+    stage_rows = []
+    if rank == 0:
+        L = None
+        from pyfaceanalysis_amd import _capi
+        L = _capi.lib()
+        h = flow._handle()
+        _capi.check(L.hg_flow_reset_profile(h.h))
+        prof_steps = max(3, min(10, args.steps))
+        for _ in range(prof_steps):
+            flow.execute_device(x.data_ptr(), in_dt, rows, x.shape[1], y.data_ptr(), np.float32, N_COLS, N_COLS,
+                                stream=stream.cuda_stream, profile=True)
+        torch.cuda.synchronize(dev)
+        stage_rows = [(nm, ms / max(cnt, 1)) for nm, ms, cnt in flow.stage_times()]
+
+    if rank == 0:
+        # parity of the timed configuration on a slice of the batch (oracle = checker only)
+        from oracle import mdp_restate
+        m = 64
+        ref = mdp_restate.execute_flow(nodes, x_host[:m].astype(np.float64))[:, :N_COLS]
+        got = y[:m].cpu().numpy().astype(np.float64)
+        max_rel = float(np.abs(got - ref).max() / np.abs(ref).max())
+
+        total_rows = rows * world
+        value = total_rows * args.steps / elapsed
+        flops_row = int(info.flops_per_row)
+        # dominant kernel = the stage with the largest average duration
+        layer_flops = synth.flops_per_row  # noqa: F841  (algorithmic figure per layer below)
+        per_layer = []
+        li = 0
+        for nd in nodes:
+            if type(nd).__name__ in ("Layer", "CloneLayer"):
+                per_layer.append(synth.flops_per_row([nd]))
+                li += 1
+        roof = None
+        if stage_rows:
+            k_idx = max(range(len(stage_rows)), key=lambda i: stage_rows[i][1])
+            k_name, k_ms = stage_rows[k_idx]
+            if info.plan_kind == 1 and k_idx < len(per_layer):
+                k_flops = per_layer[k_idx] * rows            # algorithmic FLOPs of that layer per launch
+                ach = k_flops / (k_ms * 1e-3) / 1e12
+                roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
+                        "frac": ach / PEAK_MFMA_F32_TFLOPS, "traffic": None, "kernel": k_name,
+                        "kernel_ms": k_ms, "flops_per_launch": k_flops}
+            else:
+                gb = rows * SIDE * SIDE * in_dt.itemsize / 1e9
+                ach = gb / (k_ms * 1e-3)
+                roof = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": ach / PEAK_HBM_GBS, "traffic": None, "kernel": k_name, "kernel_ms": k_ms}
+            # whole-pipeline view: all kernels of one step against the fp32 MFMA peak
+            sum_ms = sum(ms for _, ms in stage_rows)
+            roof["pipeline_tflops"] = flops_row * rows / (sum_ms * 1e-3) / 1e12
+            roof["pipeline_frac"] = roof["pipeline_tflops"] / PEAK_MFMA_F32_TFLOPS
+            roof["stages_ms"] = [round(ms, 4) for _, ms in stage_rows]
+        out = {
+            "metric": "128x128 sub-images/sec through 11L HiGSFA net",
+            "value": value, "unit": "sub-images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: U11L-128 (11-layer net, trained random-init weights), "
+                                   "%d synthetic 128x128 sub-images per GPU per step, %s input resident in HBM, "
+                                   "first %d slow features out%s" % (rows, in_dt.name, N_COLS,
+                                                                     ", RCCL all-gather" if world > 1 else ""),
+                       "rows_per_gpu": rows, "global_rows": total_rows, "plan": "fused" if info.plan_kind == 1 else "generic",
+                       "parallelism": "row-shard x%d" % world},
+            "max_rel_err_vs_oracle": max_rel,
+            "flops_per_subimage": flops_row, "padded_flops_per_subimage": int(info.padded_flops_per_row),
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(nodes)
+            out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    flow.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
