@@ -231,47 +231,41 @@ bool build_stages(const TNode& root, std::vector<FStage>& stages, std::string& w
     return true;
 }
 
-// ---- device descriptors ----------------------------------------------------------------------
-struct DNode {
-    int32_t kb_begin, kb_count;  // GEMM-1 K-blocks
-    int32_t a1_blk, b1_off;      // A1 fragments [kb][mt1] (1 KiB blocks); bias fragment [MT1][16] floats
-    int32_t k2_begin, nf;        // GEMM-2 K-blocks [mt1][nf]
-    int32_t a2_blk, b2_off;      // A2 fragments [mt1][nf][mt2]
-    int32_t out_blk, pad0, pad1, pad2;
-};
-struct DKB1 {
-    int32_t src;  // stage>0: block index inside the input batch-tile row; stage 0: entry of the offset table
-    int32_t nk;   // k-steps used (1..4)
-};
-struct DKB2 {
-    int32_t nk, func;  // func: ExpKind
-    float expo;
-    int32_t pad;
-};
-struct DChunk {
-    int32_t node_begin, node_count, run_begin, run_count;
+// ---- device side -------------------------------------------------------------------------------
+// Every stage is padded to a UNIFORM node structure (same K-block count, tile counts and
+// expansion list for all its nodes; missing pieces are zero weights), so all weight / bias
+// addresses are arithmetic on the node index and the only per-node table is the list of source
+// blocks of GEMM 1.
+constexpr int kMaxFuncs = 8;
+
+struct DChunk {   // stage 0: a group of consecutive nodes whose input columns share one LDS tile
+    int32_t node_begin, node_count, run_begin, run_count, n_cols, piece_begin, pad0, pad1;
 };
 struct DRun {
     int32_t start, len, lds_off, pad;
 };
 
 struct StageParams {
-    const DNode* nodes;
-    const DKB1* kb1;
-    const DKB2* kb2;
-    const f32x4* afrag;   // all A fragments of the stage, 64 x f32x4 per block
-    const float* bias;    // bias fragments
-    const f32x4* in;      // input activation (stage > 0)
-    f32x4* out;           // output activation
-    int32_t n_nodes, nodes_per_wg, n_tiles, nb_in, nb_out, has_exp;
-    // stage 0 only
+    const f32x4* afrag;   // [node][ A1: kb1 x MT1 | A2: MT1 x nf x MT2 ] blocks of 64 x f32x4
+    const float* bias;    // [node][ (MT1 + MT2) x 16 ]
+    const int2* kb1tab;   // [node][kb1] {source block, k-steps}           (stages > 0)
+    const f32x4* in;      // input activation, fragment order               (stages > 0)
+    f32x4* out;
+    int32_t n_nodes, kb1, nf, has_exp;
+    int32_t node_blocks, bias_floats, n_tiles, nb_in, nb_out, mto;
+    int32_t nodes_per_group, nodes_per_wg, n_chunks, tile_groups;
+    int32_t func[kMaxFuncs];
+    float expo[kMaxFuncs];
+    uint8_t nk2[kMaxMT][kMaxFuncs];
+    // stage 0
     const DChunk* chunks;
     const DRun* runs;
-    const i32x4* koff;    // [entry][g] -> 4 LDS word offsets (r = 0..3)
-    const f32x4* kmean;   // [entry][g] -> 4 pre-subtracted means
+    const int32_t* piece_col;  // per chunk piece (4 columns) -> first source column
+    const int32_t* koff;       // [node*kb1 + kb][g][r] LDS word offsets
+    const float* kmean;        // same shape: means subtracted by the loader
     const void* x;
     int64_t ldx, n_rows;
-    int32_t lds_stride, n_chunks;
+    int32_t lds_stride, nk_last, vec4, contig4;
 };
 
 __device__ __forceinline__ float pow_abs(float v, float p) {
@@ -295,21 +289,34 @@ __device__ __forceinline__ f32x4 apply_func(int func, float expo, f32x4 z) {
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-// GEMM-2 half of a node: expansion of the z accumulators in registers, second affine, store.
-template <int MT1, int MT2, int T>
-__device__ __forceinline__ void node_tail(const StageParams& P, const DNode& nd, f32x4 (&z)[MT1][T], const int (&tile)[T],
-                                          int lane) {
+template <int MT, int T>
+__device__ __forceinline__ void mfma_block(const f32x4 (&a)[MT], const f32x4 (&b)[T], f32x4 (&acc)[MT][T], int nk) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (r < nk) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int t = 0; t < T; ++t) acc[mt][t] = MFMA16(a[mt][r], b[t][r], acc[mt][t]);
+        }
+}
+
+// Second half of a node: expansion of the z accumulators in registers, second affine, store.
+// wA2 / b2 point at this node's A2 fragments (+lane) and bias-2 fragment; address space (LDS or
+// global) is resolved after inlining.
+template <int MT1, int MT2, int T, typename WP, typename BP>
+__device__ __forceinline__ void node_tail(const StageParams& P, WP wA2, BP b2, int out_blk, f32x4 (&z)[MT1][T],
+                                          const int (&tile)[T], int lane) {
     const int g = lane >> 4;
     if (!P.has_exp) {
 #pragma unroll
         for (int mt = 0; mt < MT1; ++mt)
 #pragma unroll
             for (int t = 0; t < T; ++t)
-                if (tile[t] < P.n_tiles) P.out[((size_t)tile[t] * P.nb_out + nd.out_blk + mt) * 64 + lane] = z[mt][t];
+                if (tile[t] < P.n_tiles) P.out[((size_t)tile[t] * P.nb_out + out_blk + mt) * 64 + lane] = z[mt][t];
         return;
     }
     f32x4 y[MT2][T];
-    const float* b2 = P.bias + nd.b2_off;
 #pragma unroll
     for (int mt = 0; mt < MT2; ++mt) {
         f32x4 bb = *(const f32x4*)(b2 + mt * 16 + g * 4);
@@ -318,144 +325,237 @@ __device__ __forceinline__ void node_tail(const StageParams& P, const DNode& nd,
     }
 #pragma unroll
     for (int mt1 = 0; mt1 < MT1; ++mt1) {
-        for (int fi = 0; fi < nd.nf; ++fi) {
-            const DKB2 kb = P.kb2[nd.k2_begin + mt1 * nd.nf + fi];
-            if (kb.nk == 0) continue;
-            f32x4 e[T];
-#pragma unroll
-            for (int t = 0; t < T; ++t) e[t] = apply_func(kb.func, kb.expo, z[mt1][t]);
-            const f32x4* ap = P.afrag + ((size_t)nd.a2_blk + (size_t)(mt1 * nd.nf + fi) * MT2) * 64 + lane;
+        for (int fi = 0; fi < P.nf; ++fi) {
+            const int nk = P.nk2[mt1][fi];
+            if (nk == 0) continue;
             f32x4 a[MT2];
 #pragma unroll
-            for (int mt = 0; mt < MT2; ++mt) a[mt] = ap[mt * 64];
+            for (int mt = 0; mt < MT2; ++mt) a[mt] = wA2[((mt1 * P.nf + fi) * MT2 + mt) * 64];
+            f32x4 e[T];
+            const int fk = P.func[fi];
+            const float ex = P.expo[fi];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (r < kb.nk) {
-#pragma unroll
-                    for (int mt = 0; mt < MT2; ++mt)
-#pragma unroll
-                        for (int t = 0; t < T; ++t) y[mt][t] = MFMA16(a[mt][r], e[t][r], y[mt][t]);
-                }
+            for (int t = 0; t < T; ++t) e[t] = apply_func(fk, ex, z[mt1][t]);
+            mfma_block<MT2, T>(a, e, y, nk);
         }
     }
 #pragma unroll
     for (int mt = 0; mt < MT2; ++mt)
 #pragma unroll
         for (int t = 0; t < T; ++t)
-            if (tile[t] < P.n_tiles) P.out[((size_t)tile[t] * P.nb_out + nd.out_blk + mt) * 64 + lane] = y[mt][t];
+            if (tile[t] < P.n_tiles) P.out[((size_t)tile[t] * P.nb_out + out_blk + mt) * 64 + lane] = y[mt][t];
 }
 
-// Stage > 0: input in fragment order.  WG = 4 waves; wave w owns T batch tiles; all waves walk the
-// same nodes (weights hit L1/L2), grid = node chunks x batch-tile groups.
+// Stages > 0.  A workgroup of NW waves owns NW*T batch tiles and walks a range of nodes; the
+// weights of `nodes_per_group` nodes at a time are copied once into LDS and shared by all waves
+// (A fragments by ds_read_b128); activation fragments come straight from HBM/L2 with one 16 B/lane
+// coalesced load per K-block and tile, prefetched one K-block ahead.
 template <int MT1, int MT2, int T>
-__global__ void __launch_bounds__(256) k_stage(StageParams P, int n_groups) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
-    const int chunk = blockIdx.x / n_groups, grp = blockIdx.x % n_groups;
+__global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
+    extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6, g = lane >> 4;
+    // XCD-aware decode: blocks b, b+8, ... share an XCD (and its L2); give each XCD whole node
+    // chunks so a chunk's weights are fetched into one L2 only.
+    const int xcd = blockIdx.x & 7, kq = blockIdx.x >> 3;
+    const int chunk = xcd + 8 * (kq / P.tile_groups), grp = kq % P.tile_groups;
+    if (chunk >= P.n_chunks) return;
     int tile[T];
 #pragma unroll
-    for (int t = 0; t < T; ++t) tile[t] = (grp * 4 + wave) * T + t;
-    if (tile[0] >= P.n_tiles) return;
-    const int n0 = chunk * P.nodes_per_wg;
-    const int n1 = min(n0 + P.nodes_per_wg, P.n_nodes);
-    for (int ni = n0; ni < n1; ++ni) {
-        const DNode nd = P.nodes[ni];
-        f32x4 z[MT1][T];
-        const float* b1 = P.bias + nd.b1_off;
-#pragma unroll
-        for (int mt = 0; mt < MT1; ++mt) {
-            f32x4 bb = *(const f32x4*)(b1 + mt * 16 + g * 4);
-#pragma unroll
-            for (int t = 0; t < T; ++t) z[mt][t] = bb;
-        }
-        for (int kbi = 0; kbi < nd.kb_count; ++kbi) {
-            const DKB1 kb = P.kb1[nd.kb_begin + kbi];
-            f32x4 bf[T];
-#pragma unroll
-            for (int t = 0; t < T; ++t) {
-                int tl = tile[t] < P.n_tiles ? tile[t] : tile[0];
-                bf[t] = P.in[((size_t)tl * P.nb_in + kb.src) * 64 + lane];
+    for (int t = 0; t < T; ++t) tile[t] = (grp * nw + wave) * T + t;
+    const bool active = tile[0] < P.n_tiles;
+    const int n_begin = chunk * P.nodes_per_wg;
+    const int n_end = min(n_begin + P.nodes_per_wg, P.n_nodes);
+    const int npg = P.nodes_per_group;
+    float* sb = (float*)(smem + (size_t)npg * P.node_blocks * 64);
+    int2* stab = (int2*)(sb + npg * P.bias_floats);
+
+    for (int g0 = n_begin; g0 < n_end; g0 += npg) {
+        const int gn = min(npg, n_end - g0);
+        __syncthreads();
+        {   // cooperative copy of the group's weights, 4 x 16 B in flight per thread
+            const f32x4* src = P.afrag + (size_t)g0 * P.node_blocks * 64;
+            const int nvec = gn * P.node_blocks * 64;
+            int i = tid;
+            for (; i + 3 * nthr < nvec; i += 4 * nthr) {
+                f32x4 v0 = src[i], v1 = src[i + nthr], v2 = src[i + 2 * nthr], v3 = src[i + 3 * nthr];
+                smem[i] = v0;
+                smem[i + nthr] = v1;
+                smem[i + 2 * nthr] = v2;
+                smem[i + 3 * nthr] = v3;
             }
-            const f32x4* ap = P.afrag + ((size_t)nd.a1_blk + (size_t)kbi * MT1) * 64 + lane;
-            f32x4 a[MT1];
-#pragma unroll
-            for (int mt = 0; mt < MT1; ++mt) a[mt] = ap[mt * 64];
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (r < kb.nk) {
-#pragma unroll
-                    for (int mt = 0; mt < MT1; ++mt)
-#pragma unroll
-                        for (int t = 0; t < T; ++t) z[mt][t] = MFMA16(a[mt][r], bf[t][r], z[mt][t]);
-                }
+            for (; i < nvec; i += nthr) smem[i] = src[i];
+            const float* bsrc = P.bias + (size_t)g0 * P.bias_floats;
+            for (int k = tid; k < gn * P.bias_floats; k += nthr) sb[k] = bsrc[k];
+            const int2* tsrc = P.kb1tab + (size_t)g0 * P.kb1;
+            for (int k = tid; k < gn * P.kb1; k += nthr) stab[k] = tsrc[k];
         }
-        node_tail<MT1, MT2, T>(P, nd, z, tile, lane);
+        __syncthreads();
+        if (!active) continue;
+        for (int ln = 0; ln < gn; ++ln) {
+            const f32x4* wA1 = smem + (size_t)ln * P.node_blocks * 64 + lane;
+            const f32x4* wA2 = wA1 + P.kb1 * MT1 * 64;
+            const float* b1 = sb + ln * P.bias_floats;
+            const int2* kt = stab + ln * P.kb1;
+            f32x4 z[MT1][T];
+#pragma unroll
+            for (int mt = 0; mt < MT1; ++mt) {
+                f32x4 bb = *(const f32x4*)(b1 + mt * 16 + g * 4);
+#pragma unroll
+                for (int t = 0; t < T; ++t) z[mt][t] = bb;
+            }
+            size_t trow[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) trow[t] = (size_t)(tile[t] < P.n_tiles ? tile[t] : tile[0]) * P.nb_in;
+            int2 kb = kt[0];
+            int src_blk = __builtin_amdgcn_readfirstlane(kb.x);
+            int nk = __builtin_amdgcn_readfirstlane(kb.y);
+            f32x4 bf[T], bfn[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) bf[t] = P.in[(trow[t] + src_blk) * 64 + lane];
+            for (int kbi = 0; kbi < P.kb1; ++kbi) {
+                int nkn = 0;
+                if (kbi + 1 < P.kb1) {
+                    int2 kbn = kt[kbi + 1];
+                    int sbn = __builtin_amdgcn_readfirstlane(kbn.x);
+                    nkn = __builtin_amdgcn_readfirstlane(kbn.y);
+#pragma unroll
+                    for (int t = 0; t < T; ++t) bfn[t] = P.in[(trow[t] + sbn) * 64 + lane];
+                }
+                f32x4 a[MT1];
+#pragma unroll
+                for (int mt = 0; mt < MT1; ++mt) a[mt] = wA1[(kbi * MT1 + mt) * 64];
+                mfma_block<MT1, T>(a, bf, z, nk);
+#pragma unroll
+                for (int t = 0; t < T; ++t) bf[t] = bfn[t];
+                nk = nkn;
+            }
+            node_tail<MT1, MT2, T>(P, wA2, b1 + MT1 * 16, (g0 + ln) * P.mto, z, tile, lane);
+        }
     }
 }
 
 // Stage 0: input = caller's row-major sub-image matrix.  The WG stages, for T batch tiles, the
-// column runs its node chunk needs (coalesced along the row) into LDS; each wave then takes every
-// 4th node of the chunk and reads its receptive field out of LDS via per-lane offsets.
+// column runs its node chunk needs (full 16 B/lane coalesced row segments when alignment allows)
+// into an LDS tile [sub-image][column]; each wave then takes every 4th node of the chunk and
+// reads its receptive field out of LDS (one ds_read_b128 when the four k-steps of a lane are
+// contiguous, e.g. 4-pixel-wide fields), subtracting the node's input mean on the way.
+template <typename XT> struct Vec4Load;
+template <> struct Vec4Load<float> {
+    static __device__ __forceinline__ f32x4 ld(const float* p) { return *(const f32x4*)p; }
+};
+template <> struct Vec4Load<uint8_t> {
+    static __device__ __forceinline__ f32x4 ld(const uint8_t* p) {
+        uint32_t w = *(const uint32_t*)p;
+        f32x4 v;
+        v[0] = (float)(w & 0xff);
+        v[1] = (float)((w >> 8) & 0xff);
+        v[2] = (float)((w >> 16) & 0xff);
+        v[3] = (float)(w >> 24);
+        return v;
+    }
+};
+template <> struct Vec4Load<double> {
+    static __device__ __forceinline__ f32x4 ld(const double* p) {
+        typedef double f64x2 __attribute__((ext_vector_type(2)));
+        f64x2 a = *(const f64x2*)p, b = *(const f64x2*)(p + 2);
+        f32x4 v;
+        v[0] = (float)a[0];
+        v[1] = (float)a[1];
+        v[2] = (float)b[0];
+        v[3] = (float)b[1];
+        return v;
+    }
+};
+
 template <int MT1, int MT2, int T, typename XT>
-__global__ void __launch_bounds__(256) k_stage0(StageParams P, int n_groups) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, j = lane & 15;
-    const int ci = blockIdx.x / n_groups, grp = blockIdx.x % n_groups;
+__global__ void __launch_bounds__(256) k_stage0(StageParams P) {
+    extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
+    float* lds = (float*)smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, j = lane & 15;
+    const int ci = blockIdx.x % P.n_chunks, grp = blockIdx.x / P.n_chunks;
     const DChunk ck = P.chunks[ci];
     int tile[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) tile[t] = grp * T + t;
     const XT* x = (const XT*)P.x;
     const int stride = P.lds_stride;
-    // --- stage the input runs: wave w copies sub-images w, w+4, ... of every tile
-    for (int t = 0; t < T; ++t) {
-        for (int jj = wave; jj < 16; jj += 4) {
-            const int64_t row = (int64_t)tile[t] * 16 + jj;
-            float* dst = lds + (t * 16 + jj) * stride;
-            const bool ok = tile[t] < P.n_tiles && row < P.n_rows;
-            const XT* src = x + (ok ? row : 0) * P.ldx;
-            for (int ri = 0; ri < ck.run_count; ++ri) {
-                const DRun rn = P.runs[ck.run_begin + ri];
-                for (int e = lane; e < rn.len; e += 64) dst[rn.lds_off + e] = ok ? (float)src[rn.start + e] : 0.f;
+    if (P.vec4) {
+        const int pps = ck.n_cols >> 2;          // 16-byte pieces per sub-image
+        const int total = T * 16 * pps;
+        const DRun r0 = P.runs[ck.run_begin];
+        for (int base = 0; base < total; base += 256 * 4) {
+            f32x4 v[4];
+            int dsto[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = base + k * 256 + tid;
+                dsto[k] = -1;
+                if (idx < total) {
+                    const int sj = idx / pps, pc = idx - sj * pps;
+                    const int col = ck.run_count == 1 ? r0.start + 4 * pc : P.piece_col[ck.piece_begin + pc];
+                    const int tl = tile[0] + sj / 16;
+                    const int64_t row = (int64_t)tl * 16 + (sj & 15);
+                    dsto[k] = sj * stride + 4 * pc;
+                    if (tl < P.n_tiles && row < P.n_rows)
+                        v[k] = Vec4Load<XT>::ld(x + row * P.ldx + col);
+                    else
+                        v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
             }
-            if (lane == 0) dst[stride - 1] = 0.f;  // the "zero column" padded k positions point at
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (dsto[k] >= 0) *(f32x4*)(lds + dsto[k]) = v[k];
         }
+        if (tid < T * 16) lds[tid * stride + stride - 1] = 0.f;
+    } else {
+        for (int t = 0; t < T; ++t)
+            for (int jj = wave; jj < 16; jj += 4) {
+                const int64_t row = (int64_t)tile[t] * 16 + jj;
+                float* dst = lds + (t * 16 + jj) * stride;
+                const bool ok = tile[t] < P.n_tiles && row < P.n_rows;
+                const XT* src = x + (ok ? row : 0) * P.ldx;
+                for (int ri = 0; ri < ck.run_count; ++ri) {
+                    const DRun rn = P.runs[ck.run_begin + ri];
+                    for (int e = lane; e < rn.len; e += 64) dst[rn.lds_off + e] = ok ? (float)src[rn.start + e] : 0.f;
+                }
+                if (lane == 0) dst[stride - 1] = 0.f;  // the "zero column" padded k positions point at
+            }
     }
     __syncthreads();
     for (int ni = ck.node_begin + wave; ni < ck.node_begin + ck.node_count; ni += 4) {
-        const DNode nd = P.nodes[ni];
+        const f32x4* wA1 = P.afrag + (size_t)ni * P.node_blocks * 64 + lane;
+        const f32x4* wA2 = wA1 + P.kb1 * MT1 * 64;
+        const float* b1 = P.bias + (size_t)ni * P.bias_floats;
         f32x4 z[MT1][T];
-        const float* b1 = P.bias + nd.b1_off;
 #pragma unroll
         for (int mt = 0; mt < MT1; ++mt) {
             f32x4 bb = *(const f32x4*)(b1 + mt * 16 + g * 4);
 #pragma unroll
             for (int t = 0; t < T; ++t) z[mt][t] = bb;
         }
-        for (int kbi = 0; kbi < nd.kb_count; ++kbi) {
-            const DKB1 kb = P.kb1[nd.kb_begin + kbi];
-            const i32x4 off = P.koff[(size_t)kb.src * 4 + g];
-            const f32x4 mu = P.kmean[(size_t)kb.src * 4 + g];
-            f32x4 bf[T];
-#pragma unroll
-            for (int t = 0; t < T; ++t) {
-                const float* base = lds + (t * 16 + j) * stride;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) bf[t][r] = base[off[r]] - mu[r];
-            }
-            const f32x4* ap = P.afrag + ((size_t)nd.a1_blk + (size_t)kbi * MT1) * 64 + lane;
+        for (int kbi = 0; kbi < P.kb1; ++kbi) {
+            const size_t ent = ((size_t)ni * P.kb1 + kbi) * 16 + g * 4;
+            const i32x4 off = *(const i32x4*)(P.koff + ent);
+            const f32x4 mu = *(const f32x4*)(P.kmean + ent);
             f32x4 a[MT1];
 #pragma unroll
-            for (int mt = 0; mt < MT1; ++mt) a[mt] = ap[mt * 64];
+            for (int mt = 0; mt < MT1; ++mt) a[mt] = wA1[(kbi * MT1 + mt) * 64];
+            f32x4 bf[T];
+            if (P.contig4) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (r < kb.nk) {
+                for (int t = 0; t < T; ++t) bf[t] = *(const f32x4*)(lds + (t * 16 + j) * stride + off[0]) - mu;
+            } else {
 #pragma unroll
-                    for (int mt = 0; mt < MT1; ++mt)
+                for (int t = 0; t < T; ++t) {
+                    const float* base = lds + (t * 16 + j) * stride;
 #pragma unroll
-                        for (int t = 0; t < T; ++t) z[mt][t] = MFMA16(a[mt][r], bf[t][r], z[mt][t]);
+                    for (int r = 0; r < 4; ++r) bf[t][r] = base[off[r]] - mu[r];
                 }
+            }
+            mfma_block<MT1, T>(a, bf, z, kbi == P.kb1 - 1 ? P.nk_last : 4);
         }
-        node_tail<MT1, MT2, T>(P, nd, z, tile, lane);
+        node_tail<MT1, MT2, T>(P, wA2, b1 + MT1 * 16, ni * P.mto, z, tile, lane);
     }
 }
 
@@ -474,7 +574,7 @@ __global__ void k_unpack(const float* __restrict__ act, int nb, const int32_t* _
 }
 
 // ---- launch tables -----------------------------------------------------------------------------
-typedef void (*StageFn)(StageParams, int);
+typedef void (*StageFn)(StageParams);
 
 template <int MT1, int MT2>
 StageFn pick_stage_t(int T) {
@@ -501,7 +601,7 @@ StageFn pick_stage(int mt1, int mt2, int T) {
 
 template <int MT1, int MT2, typename XT>
 StageFn pick_stage0_t(int T) {
-    if (T == 2) return k_stage0<MT1, MT2, 2, XT>;
+    if (T == 4) return k_stage0<MT1, MT2, 4, XT>;
     return k_stage0<MT1, MT2, 1, XT>;
 }
 template <int MT1, typename XT>
@@ -533,130 +633,154 @@ StageFn pick_stage0(int mt1, int mt2, int T, int x_dtype) {
 // ---- the executor --------------------------------------------------------------------------------
 inline int q_of_row(int i) { return 4 * (i & 3) + (i >> 2); }  // tile row -> tile-local feature (involution)
 
+constexpr int kStage0ChunkCols = 128;   // columns of one sub-image staged per chunk (T = 4 tiles -> ~33 KiB LDS)
+constexpr int kWeightLdsKiB = 64;       // target size of a node group's weights in LDS
+
 struct HostStage {
-    int mt1 = 1, mt2 = 1, nb_out = 0, nb_in = 0, n_nodes = 0;
-    bool has_exp = false;
-    std::vector<DNode> nodes;
-    std::vector<DKB1> kb1;
-    std::vector<DKB2> kb2;
-    std::vector<float> afrag;  // blocks of 256 floats
-    std::vector<float> bias;
+    int mt1 = 1, mt2 = 1, mto = 1, nb_out = 0, nb_in = 0, n_nodes = 0, kb1 = 0, nf = 0;
+    int node_blocks = 0, bias_floats = 0, nk_last = 4;
+    bool has_exp = false, contig4 = false, vec_ok = false;
+    std::vector<ExpFunc> funcs;
+    uint8_t nk2[kMaxMT][kMaxFuncs] = {};
+    std::vector<float> afrag, bias;
+    std::vector<int32_t> kb1tab;  // int2 pairs
     // stage 0
     std::vector<DChunk> chunks;
     std::vector<DRun> runs;
-    std::vector<int32_t> koff;   // [entry][g][r]
+    std::vector<int32_t> piece_col, koff;
     std::vector<float> kmean;
     int lds_stride = 0;
-    int64_t mfma_per_tile = 0;   // MFMA instructions per batch tile (padded work)
+    int64_t mfma_per_tile = 0;
     std::string name;
-    // device
-    DevBuf d_nodes, d_kb1, d_kb2, d_afrag, d_bias, d_chunks, d_runs, d_koff, d_kmean;
+    DevBuf d_afrag, d_bias, d_kb1tab, d_chunks, d_runs, d_piece, d_koff, d_kmean;
 };
 
 class FusedExecutor : public Executor {
 public:
     FusedExecutor(const TNode& root, std::vector<FStage>&& fs) : in_dim_(root.in_dim), out_dim_(root.out_dim) {
-        // feature -> (block, q) maps of the previous stage's output frame
-        std::vector<int32_t> prev_blk, prev_q;  // per previous-frame column
+        std::vector<int32_t> prev_blk, prev_q;  // per column of the previous stage's output frame
         int prev_nb = 0;
         for (size_t si = 0; si < fs.size(); ++si) {
             FStage& st = fs[si];
             stages_.emplace_back();
             HostStage& hs = stages_.back();
-            hs.n_nodes = (int)st.nodes.size();
+            const int n = (int)st.nodes.size();
+            hs.n_nodes = n;
             hs.has_exp = st.nodes[0].has_exp;
+            hs.funcs = st.nodes[0].funcs;
+            hs.nf = (int)hs.funcs.size();
+            int p_max = 0;
             for (auto& nd : st.nodes) {
-                if (nd.has_exp != hs.has_exp) fail(HG_ERR_FORMAT, "fused: mixed node forms in one layer");
                 hs.mt1 = std::max(hs.mt1, (nd.A1.out + 15) / 16);
                 if (nd.has_exp) hs.mt2 = std::max(hs.mt2, (nd.A2.out + 15) / 16);
+                p_max = std::max(p_max, nd.A1.out);
             }
             if (!hs.has_exp) hs.mt2 = 1;
+            hs.mto = hs.has_exp ? hs.mt2 : hs.mt1;
             hs.nb_in = prev_nb;
-            const int mto = hs.has_exp ? hs.mt2 : hs.mt1;
+            for (int mt1 = 0; mt1 < hs.mt1; ++mt1)
+                for (int fi = 0; fi < hs.nf; ++fi) {
+                    int valid = std::max(0, std::min(16, hs.funcs[fi].used(p_max) - 16 * mt1));
+                    hs.nk2[mt1][fi] = (uint8_t)((valid + 3) / 4);
+                }
+
+            // ---- per node: K-blocks of GEMM 1 and, for every (kblock, q), the consumer input positions
+            struct NodeK {
+                std::vector<int> src, nk;
+                std::vector<std::vector<int>> kpos;  // [kb*16 + q] -> positions c
+            };
+            std::vector<NodeK> nks(n);
             if (si == 0) plan_stage0_inputs(st, hs);
-            std::vector<int32_t> cur_blk, cur_q;
-            int out_blk = 0;
-            for (size_t ni = 0; ni < st.nodes.size(); ++ni) {
+            for (int ni = 0; ni < n; ++ni) {
                 FNode& nd = st.nodes[ni];
-                DNode dn{};
-                // ---- GEMM 1 -------------------------------------------------------------------
-                const int p = nd.A1.out;
-                // K-blocks and, for every (kblock, r, g), the list of consumer input positions
-                std::vector<std::vector<int>> kpos;  // [kb*16 + 4r+g] -> positions c
-                std::vector<DKB1> kbs;
-                std::vector<double> bias1 = nd.A1.b;
+                NodeK& K = nks[ni];
                 if (si == 0) {
                     const int nkb = (nd.in_dim + 15) / 16;
                     for (int kb = 0; kb < nkb; ++kb) {
                         int valid = std::min(16, nd.in_dim - kb * 16);
-                        kbs.push_back(DKB1{s0_entry_base_[ni] + kb, (valid + 3) / 4});
+                        K.src.push_back(0);
+                        K.nk.push_back((valid + 3) / 4);
                         for (int q = 0; q < 16; ++q) {
-                            kpos.emplace_back();
-                            if (q < valid) kpos.back().push_back(kb * 16 + q);
+                            K.kpos.emplace_back();
+                            if (q < valid) K.kpos.back().push_back(kb * 16 + q);
                         }
                     }
-                    // means are subtracted by the loader in fp32; the fp64 remainder goes into the bias
-                    for (int c = 0; c < nd.in_dim; ++c) {
-                        double rem = nd.A1.a[c] - (double)(float)nd.A1.a[c];
-                        for (int o = 0; o < p; ++o) bias1[o] -= rem * nd.A1.W[(size_t)c * p + o];
-                    }
                 } else {
-                    std::map<int, int> blk_index;  // source block -> local kb index
+                    std::map<int, int> blk_index;
                     for (int c = 0; c < nd.in_dim; ++c) {
                         int pc = st.conn[nd.in_off + c];
                         int blk = prev_blk[pc], q = prev_q[pc];
                         auto it = blk_index.find(blk);
                         int kb;
                         if (it == blk_index.end()) {
-                            kb = (int)kbs.size();
+                            kb = (int)K.src.size();
                             blk_index[blk] = kb;
-                            kbs.push_back(DKB1{blk, 0});
-                            for (int qq = 0; qq < 16; ++qq) kpos.emplace_back();
+                            K.src.push_back(blk);
+                            K.nk.push_back(0);
+                            for (int qq = 0; qq < 16; ++qq) K.kpos.emplace_back();
                         } else {
                             kb = it->second;
                         }
-                        kpos[kb * 16 + q].push_back(c);
-                        kbs[kb].nk = std::max(kbs[kb].nk, q / 4 + 1);
+                        K.kpos[kb * 16 + q].push_back(c);
+                        K.nk[kb] = std::max(K.nk[kb], q / 4 + 1);
                     }
-                    for (int c = 0; c < nd.in_dim; ++c)  // (x - a) W + b = x W + (b - a W)
-                        for (int o = 0; o < p; ++o) bias1[o] -= nd.A1.a[c] * nd.A1.W[(size_t)c * p + o];
                 }
-                dn.kb_begin = (int)hs.kb1.size();
-                dn.kb_count = (int)kbs.size();
-                dn.a1_blk = (int)(hs.afrag.size() / 256);
-                for (size_t kb = 0; kb < kbs.size(); ++kb) {
-                    hs.kb1.push_back(kbs[kb]);
-                    hs.mfma_per_tile += (int64_t)kbs[kb].nk * hs.mt1;
+                hs.kb1 = std::max(hs.kb1, (int)K.src.size());
+            }
+            hs.node_blocks = hs.kb1 * hs.mt1 + (hs.has_exp ? hs.mt1 * hs.nf * hs.mt2 : 0);
+            hs.bias_floats = (hs.mt1 + (hs.has_exp ? hs.mt2 : 0)) * 16;
+            hs.afrag.assign((size_t)n * hs.node_blocks * 256, 0.f);
+            hs.bias.assign((size_t)n * hs.bias_floats, 0.f);
+            if (si > 0) hs.kb1tab.assign((size_t)n * hs.kb1 * 2, 0);
+
+            std::vector<int32_t> cur_blk, cur_q;
+            for (int ni = 0; ni < n; ++ni) {
+                FNode& nd = st.nodes[ni];
+                NodeK& K = nks[ni];
+                const int p = nd.A1.out;
+                float* wnode = hs.afrag.data() + (size_t)ni * hs.node_blocks * 256;
+                float* bnode = hs.bias.data() + (size_t)ni * hs.bias_floats;
+                // bias 1: (x - a) W + b = x W + (b - a W); stage 0 subtracts fl32(a) in the loader and
+                // keeps only the fp64 remainder here
+                std::vector<double> bias1 = nd.A1.b;
+                for (int c = 0; c < nd.in_dim; ++c) {
+                    double av = si == 0 ? nd.A1.a[c] - (double)(float)nd.A1.a[c] : nd.A1.a[c];
+                    if (av == 0.0) continue;
+                    for (int o = 0; o < p; ++o) bias1[o] -= av * nd.A1.W[(size_t)c * p + o];
+                }
+                for (size_t kb = 0; kb < K.src.size(); ++kb) {
+                    if (si > 0) {
+                        hs.kb1tab[((size_t)ni * hs.kb1 + kb) * 2] = K.src[kb];
+                        hs.kb1tab[((size_t)ni * hs.kb1 + kb) * 2 + 1] = K.nk[kb];
+                    }
+                    hs.mfma_per_tile += (int64_t)K.nk[kb] * hs.mt1;
                     for (int mt = 0; mt < hs.mt1; ++mt) {
-                        size_t base = hs.afrag.size();
-                        hs.afrag.resize(base + 256, 0.f);
+                        float* blk = wnode + ((size_t)kb * hs.mt1 + mt) * 256;
                         for (int lane = 0; lane < 64; ++lane) {
                             int i = lane & 15, gg = lane >> 4;
                             int fo = 16 * mt + q_of_row(i);
                             if (fo >= p) continue;
                             for (int r = 0; r < 4; ++r) {
                                 double w = 0;
-                                for (int c : kpos[kb * 16 + 4 * r + gg]) w += nd.A1.W[(size_t)c * p + fo];
-                                hs.afrag[base + lane * 4 + r] = (float)w;
+                                for (int c : K.kpos[kb * 16 + 4 * r + gg]) w += nd.A1.W[(size_t)c * p + fo];
+                                blk[lane * 4 + r] = (float)w;
                             }
                         }
                     }
                 }
-                dn.b1_off = (int)hs.bias.size();
+                if (si > 0)  // padded K-blocks: any valid source block, zero k-steps
+                    for (int kb = (int)K.src.size(); kb < hs.kb1; ++kb) hs.kb1tab[((size_t)ni * hs.kb1 + kb) * 2] = K.src[0];
+                if (si == 0 && (int)K.src.size() == hs.kb1) hs.nk_last = std::max(ni == 0 ? 0 : hs.nk_last, K.nk.back());
                 for (int mt = 0; mt < hs.mt1; ++mt)
                     for (int gg = 0; gg < 4; ++gg)
                         for (int r = 0; r < 4; ++r) {
                             int fo = 16 * mt + 4 * r + gg;
-                            hs.bias.push_back(fo < p ? (float)bias1[fo] : 0.f);
+                            bnode[mt * 16 + gg * 4 + r] = fo < p ? (float)bias1[fo] : 0.f;
                         }
-                // ---- GEMM 2 -------------------------------------------------------------------
                 int n_out = p;
                 if (hs.has_exp) {
                     const int s = nd.A2.out;
                     n_out = s;
-                    dn.nf = (int)nd.funcs.size();
-                    dn.k2_begin = (int)hs.kb2.size();
-                    dn.a2_blk = (int)(hs.afrag.size() / 256);
                     std::vector<int> foff(nd.funcs.size());
                     int eo = 0;
                     for (size_t fi = 0; fi < nd.funcs.size(); ++fi) {
@@ -667,17 +791,13 @@ public:
                     std::vector<double> bias2 = nd.A2.b;
                     for (int c = 0; c < nd.A2.in; ++c)
                         for (int o = 0; o < s; ++o) bias2[o] -= nd.A2.a[c] * nd.A2.W[(size_t)c * s + o];
+                    float* w2 = wnode + (size_t)hs.kb1 * hs.mt1 * 256;
                     for (int mt1 = 0; mt1 < hs.mt1; ++mt1)
-                        for (size_t fi = 0; fi < nd.funcs.size(); ++fi) {
-                            const ExpFunc& f = nd.funcs[fi];
-                            int used = f.used(p);
-                            int valid = std::max(0, std::min(16, used - 16 * mt1));
-                            DKB2 kb{(valid + 3) / 4, (int32_t)f.kind, (float)f.expo, 0};
-                            hs.kb2.push_back(kb);
-                            hs.mfma_per_tile += (int64_t)kb.nk * hs.mt2;
+                        for (int fi = 0; fi < hs.nf; ++fi) {
+                            const int used = nd.funcs[fi].used(p);
+                            hs.mfma_per_tile += (int64_t)hs.nk2[mt1][fi] * hs.mt2;
                             for (int mt2 = 0; mt2 < hs.mt2; ++mt2) {
-                                size_t base = hs.afrag.size();
-                                hs.afrag.resize(base + 256, 0.f);
+                                float* blk = w2 + ((size_t)(mt1 * hs.nf + fi) * hs.mt2 + mt2) * 256;
                                 for (int lane = 0; lane < 64; ++lane) {
                                     int i = lane & 15, gg = lane >> 4;
                                     int fo = 16 * mt2 + q_of_row(i);
@@ -685,39 +805,35 @@ public:
                                     for (int r = 0; r < 4; ++r) {
                                         int fz = 16 * mt1 + 4 * r + gg;
                                         if (fz >= used) continue;
-                                        hs.afrag[base + lane * 4 + r] = (float)nd.A2.W[(size_t)(foff[fi] + fz) * s + fo];
+                                        blk[lane * 4 + r] = (float)nd.A2.W[(size_t)(foff[fi] + fz) * s + fo];
                                     }
                                 }
                             }
                         }
-                    dn.b2_off = (int)hs.bias.size();
                     for (int mt = 0; mt < hs.mt2; ++mt)
                         for (int gg = 0; gg < 4; ++gg)
                             for (int r = 0; r < 4; ++r) {
                                 int fo = 16 * mt + 4 * r + gg;
-                                hs.bias.push_back(fo < s ? (float)bias2[fo] : 0.f);
+                                bnode[hs.mt1 * 16 + mt * 16 + gg * 4 + r] = fo < s ? (float)bias2[fo] : 0.f;
                             }
                 }
-                dn.out_blk = out_blk;
                 for (int f = 0; f < n_out; ++f) {
-                    cur_blk.push_back(out_blk + f / 16);
+                    cur_blk.push_back(ni * hs.mto + f / 16);
                     cur_q.push_back(f % 16);
                 }
-                out_blk += mto;
-                hs.nodes.push_back(dn);
             }
-            hs.nb_out = out_blk;
+            hs.nb_out = n * hs.mto;
             prev_blk.swap(cur_blk);
             prev_q.swap(cur_q);
             prev_nb = hs.nb_out;
             max_nb_ = std::max(max_nb_, hs.nb_out);
             padded_flops_ += hs.mfma_per_tile * 2048 / 16;
             std::ostringstream os;
-            os << "fused stage " << si << ": " << hs.n_nodes << " nodes, MT " << hs.mt1 << "x" << hs.mt2 << ", "
-               << hs.mfma_per_tile << " MFMA/tile, " << hs.afrag.size() * 4 / 1024 << " KiB weights, out " << hs.nb_out << " blocks/tile";
+            os << "fused stage " << si << ": " << hs.n_nodes << " nodes, K-blocks " << hs.kb1 << ", tiles " << hs.mt1 << "x" << hs.mt2
+               << ", " << hs.mfma_per_tile << " MFMA/tile, " << hs.afrag.size() * 4 / 1024 << " KiB weights, out " << hs.nb_out
+               << " blocks/tile";
             hs.name = os.str();
         }
-        // final frame: column -> offset inside a batch-tile row
         col_base_.resize(out_dim_);
         for (int c = 0; c < out_dim_; ++c) {
             int q = prev_q[c];
@@ -746,22 +862,18 @@ public:
 
     void to_device() override {
         for (auto& s : stages_) {
-            s.d_nodes.upload(s.nodes.data(), s.nodes.size() * sizeof(DNode));
-            s.d_kb1.upload(s.kb1.data(), s.kb1.size() * sizeof(DKB1));
-            if (!s.kb2.empty()) s.d_kb2.upload(s.kb2.data(), s.kb2.size() * sizeof(DKB2));
             s.d_afrag.upload(s.afrag.data(), s.afrag.size() * 4);
             s.d_bias.upload(s.bias.data(), s.bias.size() * 4);
+            if (!s.kb1tab.empty()) s.d_kb1tab.upload(s.kb1tab.data(), s.kb1tab.size() * 4);
             if (!s.chunks.empty()) {
                 s.d_chunks.upload(s.chunks.data(), s.chunks.size() * sizeof(DChunk));
                 s.d_runs.upload(s.runs.data(), s.runs.size() * sizeof(DRun));
+                s.d_piece.upload(s.piece_col.data(), std::max<size_t>(s.piece_col.size(), 1) * 4);
                 s.d_koff.upload(s.koff.data(), s.koff.size() * 4);
                 s.d_kmean.upload(s.kmean.data(), s.kmean.size() * 4);
             }
         }
         d_col_base_.upload(col_base_.data(), col_base_.size() * 4);
-        int dev = 0;
-        HG_HIP(hipGetDevice(&dev));
-        for (int mt1 = 1; mt1 <= kMaxMT; ++mt1) (void)mt1;
     }
 
     void reserve(int64_t rows) override {
@@ -783,46 +895,77 @@ public:
         for (size_t si = 0; si < stages_.size(); ++si) {
             HostStage& s = stages_[si];
             StageParams P{};
-            P.nodes = (const DNode*)s.d_nodes.p;
-            P.kb1 = (const DKB1*)s.d_kb1.p;
-            P.kb2 = (const DKB2*)s.d_kb2.p;
             P.afrag = (const f32x4*)s.d_afrag.p;
             P.bias = (const float*)s.d_bias.p;
+            P.kb1tab = (const int2*)s.d_kb1tab.p;
             P.in = cur;
             P.out = nxt;
             P.n_nodes = s.n_nodes;
+            P.kb1 = s.kb1;
+            P.nf = s.nf;
+            P.has_exp = s.has_exp ? 1 : 0;
+            P.node_blocks = s.node_blocks;
+            P.bias_floats = s.bias_floats;
             P.n_tiles = n_tiles;
             P.nb_in = s.nb_in;
             P.nb_out = s.nb_out;
-            P.has_exp = s.has_exp ? 1 : 0;
+            P.mto = s.mto;
+            for (int fi = 0; fi < s.nf; ++fi) {
+                P.func[fi] = (int32_t)s.funcs[fi].kind;
+                P.expo[fi] = (float)s.funcs[fi].expo;
+            }
+            memcpy(P.nk2, s.nk2, sizeof P.nk2);
             if (si == 0) {
                 P.chunks = (const DChunk*)s.d_chunks.p;
                 P.runs = (const DRun*)s.d_runs.p;
-                P.koff = (const i32x4*)s.d_koff.p;
-                P.kmean = (const f32x4*)s.d_kmean.p;
+                P.piece_col = (const int32_t*)s.d_piece.p;
+                P.koff = (const int32_t*)s.d_koff.p;
+                P.kmean = (const float*)s.d_kmean.p;
                 P.x = x;
                 P.ldx = ldx;
                 P.n_rows = n;
                 P.lds_stride = s.lds_stride;
+                P.nk_last = s.nk_last;
+                P.contig4 = s.contig4 ? 1 : 0;
                 P.n_chunks = (int)s.chunks.size();
-                const int T = n_tiles >= 2 ? 2 : 1;
+                const size_t esz = dtype_size(x_dtype);
+                const size_t valign = x_dtype == HG_U8 ? 4 : 16;
+                P.vec4 = (s.vec_ok && ldx % 4 == 0 && ((uintptr_t)x % valign) == 0 && (ldx * esz) % valign == 0) ? 1 : 0;
+                const int T = (n_tiles >= 4 && s.mt1 * s.mt2 <= 4) ? 4 : 1;
                 const int groups = (n_tiles + T - 1) / T;
                 const int64_t blocks = (int64_t)groups * P.n_chunks;
                 if (blocks > 0x7fffffffll) fail(HG_ERR_ARG, "batch too large");
                 size_t lds_bytes = (size_t)T * 16 * s.lds_stride * 4;
                 StageFn fn = pick_stage0(s.mt1, s.mt2, T, x_dtype);
-                hipLaunchKernelGGL(fn, (unsigned)blocks, 256, lds_bytes, st, P, groups);
+                set_lds_limit(fn, lds_bytes);
+                hipLaunchKernelGGL(fn, (unsigned)blocks, 256, lds_bytes, st, P);
             } else {
-                // enough workgroups to fill 256 CUs several times over when the batch allows
-                int T = ((int64_t)n_tiles * s.n_nodes >= 8 * 1024) ? 2 : 1;
-                int groups = (n_tiles + 4 * T - 1) / (4 * T);
-                int per_wg = (int)std::max<int64_t>(1, (int64_t)s.n_nodes * groups / 2048);
-                P.nodes_per_wg = per_wg;
-                int chunks = (s.n_nodes + per_wg - 1) / per_wg;
-                const int64_t blocks = (int64_t)groups * chunks;
+                // node groups sized so a group's weights are ~64 KiB of LDS (always >= 1 node)
+                const int npg = std::max(1, std::min(s.n_nodes, kWeightLdsKiB / std::max(1, s.node_blocks)));
+                const int n_groups = (s.n_nodes + npg - 1) / npg;
+                // waves x tiles per workgroup: the largest shape that still yields >= 512 workgroups
+                static const int shapes[][2] = {{8, 2}, {4, 2}, {4, 1}, {2, 1}, {1, 1}};
+                int nw = 1, T = 1;
+                for (auto& sh : shapes) {
+                    nw = sh[0];
+                    T = sh[1];
+                    int64_t tg = (n_tiles + nw * T - 1) / (nw * T);
+                    if (nw * T <= n_tiles && tg * n_groups >= 512) break;
+                    if (nw * T <= n_tiles && sh[0] == 1) break;
+                }
+                while (nw * T > std::max(n_tiles, 1) && nw > 1) nw >>= 1;
+                const int tile_groups = (n_tiles + nw * T - 1) / (nw * T);
+                int groups_per_wg = (int)std::max<int64_t>(1, (int64_t)n_groups * tile_groups / 4096);
+                P.nodes_per_group = npg;
+                P.nodes_per_wg = npg * groups_per_wg;
+                P.n_chunks = (s.n_nodes + P.nodes_per_wg - 1) / P.nodes_per_wg;
+                P.tile_groups = tile_groups;
+                const int64_t blocks = (int64_t)((P.n_chunks + 7) / 8) * 8 * tile_groups;
                 if (blocks > 0x7fffffffll) fail(HG_ERR_ARG, "batch too large");
+                size_t lds_bytes = (size_t)npg * s.node_blocks * 1024 + (size_t)npg * s.bias_floats * 4 + (size_t)npg * s.kb1 * 8;
                 StageFn fn = pick_stage(s.mt1, s.mt2, T);
-                hipLaunchKernelGGL(fn, (unsigned)blocks, 256, 0, st, P, groups);
+                set_lds_limit(fn, lds_bytes);
+                hipLaunchKernelGGL(fn, (unsigned)blocks, nw * 64, lds_bytes, st, P);
             }
             std::swap(cur, nxt);
             if (ev) HG_HIP(hipEventRecord(ev[e++], st));
@@ -846,22 +989,38 @@ public:
         bufB_.free();
         d_col_base_.free();
         for (auto& s : stages_) {
-            s.d_nodes.free(); s.d_kb1.free(); s.d_kb2.free(); s.d_afrag.free(); s.d_bias.free();
-            s.d_chunks.free(); s.d_runs.free(); s.d_koff.free(); s.d_kmean.free();
+            s.d_afrag.free(); s.d_bias.free(); s.d_kb1tab.free(); s.d_chunks.free();
+            s.d_runs.free(); s.d_piece.free(); s.d_koff.free(); s.d_kmean.free();
         }
         cap_rows_ = 0;
     }
 
 private:
+    void set_lds_limit(StageFn fn, size_t bytes) {
+        if (bytes <= 64 * 1024) return;
+        if (bytes > 160 * 1024) fail(HG_ERR_FORMAT, "fused: a node needs %zu bytes of LDS (> 160 KiB)", bytes);
+        auto it = lds_set_.find((const void*)fn);
+        if (it != lds_set_.end() && it->second >= bytes) return;
+        HG_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+        lds_set_[(const void*)fn] = 160 * 1024;
+    }
+
     // Stage 0: group consecutive nodes into chunks whose distinct input columns fit the LDS tile,
     // turn each chunk's column set into contiguous runs, and record for every node input position
     // its word offset inside the staged row.
     void plan_stage0_inputs(const FStage& st, HostStage& hs) {
         const int n = (int)st.nodes.size();
-        s0_entry_base_.assign(n, 0);
-        int max_cols = 0;
-        int ni = 0;
-        int entry = 0;
+        int kb1 = 0, max_in = 0;
+        for (auto& nd : st.nodes) {
+            kb1 = std::max(kb1, (nd.in_dim + 15) / 16);
+            max_in = std::max(max_in, nd.in_dim);
+        }
+        const int col_budget = std::max(kStage0ChunkCols, (max_in + 3) / 4 * 4);
+        if (col_budget > 2048) fail(HG_ERR_FORMAT, "fused: first-layer node with %d inputs", max_in);
+        hs.koff.assign((size_t)n * kb1 * 16, -1);
+        hs.kmean.assign((size_t)n * kb1 * 16, 0.f);
+        int max_cols = 0, ni = 0;
+        bool vec_ok = true, contig = true;
         while (ni < n) {
             std::vector<int32_t> cols;
             int n1 = ni;
@@ -871,59 +1030,69 @@ private:
                 for (int c = 0; c < nd.in_dim; ++c) c2.push_back(st.conn[nd.in_off + c]);
                 std::sort(c2.begin(), c2.end());
                 c2.erase(std::unique(c2.begin(), c2.end()), c2.end());
-                if ((int)c2.size() > kStage0MaxCols) break;
+                if ((int)c2.size() > col_budget && n1 > ni) break;
                 cols.swap(c2);
                 ++n1;
-                if (n1 - ni >= 64) break;
             }
-            if (n1 == ni) fail(HG_ERR_FORMAT, "fused: first-layer node with more than %d inputs", kStage0MaxCols);
-            DChunk ck{ni, n1 - ni, (int)hs.runs.size(), 0};
+            DChunk ck{ni, n1 - ni, (int)hs.runs.size(), 0, 0, (int)hs.piece_col.size(), 0, 0};
             std::map<int32_t, int32_t> lds_of;
             int off = 0;
             for (size_t i = 0; i < cols.size();) {
                 size_t k = i + 1;
                 while (k < cols.size() && cols[k] == cols[k - 1] + 1) ++k;
-                hs.runs.push_back(DRun{cols[i], (int)(k - i), off, 0});
+                const int len = (int)(k - i);
+                hs.runs.push_back(DRun{cols[i], len, off, 0});
+                if (cols[i] % 4 || len % 4) vec_ok = false;
                 for (size_t m = i; m < k; ++m) lds_of[cols[m]] = off + (int)(m - i);
-                off += (int)(k - i);
+                for (int pc = 0; pc + 3 < len; pc += 4) hs.piece_col.push_back(cols[i] + pc);
+                off += len;
                 i = k;
                 ++ck.run_count;
             }
+            ck.n_cols = off;
             max_cols = std::max(max_cols, off);
             for (int k = ni; k < n1; ++k) {
                 const FNode& nd = st.nodes[k];
-                s0_entry_base_[k] = entry;
-                const int nkb = (nd.in_dim + 15) / 16;
-                for (int kb = 0; kb < nkb; ++kb, ++entry)
+                for (int kb = 0; kb < kb1; ++kb)
                     for (int g = 0; g < 4; ++g)
                         for (int r = 0; r < 4; ++r) {
                             int c = kb * 16 + 4 * r + g;
+                            size_t e = (((size_t)k * kb1 + kb) * 4 + g) * 4 + r;
                             if (c < nd.in_dim) {
-                                hs.koff.push_back(lds_of[st.conn[nd.in_off + c]]);
-                                hs.kmean.push_back((float)nd.A1.a[c]);
-                            } else {
-                                hs.koff.push_back(-1);  // patched to the zero column below
-                                hs.kmean.push_back(0.f);
+                                hs.koff[e] = lds_of[st.conn[nd.in_off + c]];
+                                hs.kmean[e] = (float)nd.A1.a[c];
                             }
                         }
             }
             hs.chunks.push_back(ck);
             ni = n1;
         }
-        // row stride: >= max_cols + 1 (zero column), == 2 (mod 32) so the 16 sub-images x 2 lane
-        // groups of one ds_read_b32 half-wave hit 32 distinct banks
+        // Row stride of the LDS tile: >= max_cols + 1 (last word = the zero column padded k positions
+        // read), == 4 (mod 64) words so that the 16 sub-images of a ds_read_b128 lane group land on 16
+        // distinct 16-byte slots of the 256-byte bank row (rows stay 16-byte aligned).
         int stride = max_cols + 1;
-        while (stride % 32 != 2) ++stride;
+        while (stride % 64 != 4) ++stride;
         hs.lds_stride = stride;
-        for (auto& o : hs.koff)
-            if (o < 0) o = stride - 1;
+        for (size_t e = 0; e < hs.koff.size(); e += 4) {
+            bool any_pad = false;
+            for (int r = 0; r < 4; ++r)
+                if (hs.koff[e + r] < 0) {
+                    hs.koff[e + r] = stride - 1;
+                    any_pad = true;
+                }
+            if (any_pad || hs.koff[e] % 4) contig = false;
+            for (int r = 1; r < 4; ++r)
+                if (hs.koff[e + r] != hs.koff[e] + r) contig = false;
+        }
+        hs.contig4 = contig;
+        hs.vec_ok = vec_ok;
     }
 
     int in_dim_, out_dim_;
     std::vector<HostStage> stages_;
-    std::vector<int32_t> s0_entry_base_;
     std::vector<int32_t> col_base_;
     DevBuf d_col_base_, bufA_, bufB_;
+    std::map<const void*, size_t> lds_set_;
     int max_nb_ = 0;
     int64_t padded_flops_ = 0, cap_rows_ = 0;
 };
@@ -937,13 +1106,21 @@ std::unique_ptr<Executor> make_fused_executor(const TNode& root, std::string* wh
         if (why_not) *why_not = why;
         return nullptr;
     }
-    for (size_t i = 0; i < stages.size(); ++i) {
-        bool he = stages[i].nodes[0].has_exp;
-        for (auto& n : stages[i].nodes)
-            if (n.has_exp != he) {
-                if (why_not) *why_not = "layer mixes node forms";
+    for (auto& st : stages) {
+        const FNode& f0 = st.nodes[0];
+        if (f0.funcs.size() > (size_t)kMaxFuncs) {
+            if (why_not) *why_not = "more than 8 expansion functions";
+            return nullptr;
+        }
+        for (auto& n : st.nodes) {
+            bool same = n.has_exp == f0.has_exp && n.funcs.size() == f0.funcs.size();
+            for (size_t i = 0; same && i < n.funcs.size(); ++i)
+                same = n.funcs[i].kind == f0.funcs[i].kind && n.funcs[i].expo == f0.funcs[i].expo && n.funcs[i].sel == f0.funcs[i].sel;
+            if (!same) {
+                if (why_not) *why_not = "nodes of one layer use different expansions";
                 return nullptr;
             }
+        }
     }
     if (why_not) why_not->clear();
     return std::make_unique<FusedExecutor>(root, std::move(stages));
