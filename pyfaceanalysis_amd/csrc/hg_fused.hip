@@ -414,14 +414,13 @@ __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
 #pragma unroll
             for (int t = 0; t < T; ++t) bf[t] = P.in[(trow[t] + src_blk) * 64 + lane];
             for (int kbi = 0; kbi < P.kb1; ++kbi) {
-                int nkn = 0;
-                if (kbi + 1 < P.kb1) {
-                    int2 kbn = kt[kbi + 1];
-                    int sbn = __builtin_amdgcn_readfirstlane(kbn.x);
-                    nkn = __builtin_amdgcn_readfirstlane(kbn.y);
+                // unconditional prefetch of the next K-block's activation fragments (the last
+                // iteration re-reads its own block) so the wait below can be a counted vmcnt
+                const int2 kbn = kt[kbi + 1 < P.kb1 ? kbi + 1 : kbi];
+                const int sbn = __builtin_amdgcn_readfirstlane(kbn.x);
+                const int nkn = __builtin_amdgcn_readfirstlane(kbn.y);
 #pragma unroll
-                    for (int t = 0; t < T; ++t) bfn[t] = P.in[(trow[t] + sbn) * 64 + lane];
-                }
+                for (int t = 0; t < T; ++t) bfn[t] = P.in[(trow[t] + sbn) * 64 + lane];
                 f32x4 a[MT1];
 #pragma unroll
                 for (int mt = 0; mt < MT1; ++mt) a[mt] = wA1[(kbi * MT1 + mt) * 64];
@@ -944,14 +943,17 @@ public:
                 const int npg = std::max(1, std::min(s.n_nodes, kWeightLdsKiB / std::max(1, s.node_blocks)));
                 const int n_groups = (s.n_nodes + npg - 1) / npg;
                 // waves x tiles per workgroup: the largest shape that still yields >= 512 workgroups
-                static const int shapes[][2] = {{8, 2}, {4, 2}, {4, 1}, {2, 1}, {1, 1}};
-                int nw = 1, T = 1;
+                // waves x tiles per workgroup: the largest shape that still gives every CU a
+                // workgroup; never fewer than 4 waves to copy a node's weights unless the batch is tiny
+                static const int shapes[][2] = {{8, 2}, {4, 2}, {4, 1}};
+                int nw = 4, T = 1;
                 for (auto& sh : shapes) {
-                    nw = sh[0];
-                    T = sh[1];
-                    int64_t tg = (n_tiles + nw * T - 1) / (nw * T);
-                    if (nw * T <= n_tiles && tg * n_groups >= 512) break;
-                    if (nw * T <= n_tiles && sh[0] == 1) break;
+                    int64_t tg = (n_tiles + sh[0] * sh[1] - 1) / (sh[0] * sh[1]);
+                    if (sh[0] * sh[1] <= n_tiles && tg * n_groups >= 256) {
+                        nw = sh[0];
+                        T = sh[1];
+                        break;
+                    }
                 }
                 while (nw * T > std::max(n_tiles, 1) && nw > 1) nw >>= 1;
                 const int tile_groups = (n_tiles + nw * T - 1) / (nw * T);

@@ -156,10 +156,12 @@ class Flow(object):
         x = np.asarray(x)
         if x.ndim != 2:
             raise _capi.NodeException("x has rank %d, should be 2" % x.ndim)
-        h = self._handle(nodenr)
-        out_dim = self.flow[len(self.flow) - 1 if nodenr is None else nodenr].output_dim
         if x.shape[1] != self.input_dim:
             raise _capi.NodeException("x has dimension %d, should be %d" % (x.shape[1], self.input_dim))
+        if nodenr is not None and not 0 <= int(nodenr) < len(self.flow):
+            raise ValueError("nodenr %r out of range for a flow of %d nodes" % (nodenr, len(self.flow)))
+        out_dim = self.flow[len(self.flow) - 1 if nodenr is None else nodenr].output_dim
+        h = self._handle(nodenr)
         code = _capi.np_dtype_code(x.dtype)
         if code is None:
             x = x.astype(np.float64)

@@ -1,0 +1,60 @@
+"""Shared test helpers: random (untrained) flows with awkward structure."""
+import numpy as np
+
+from pyfaceanalysis_amd import nodes as N
+
+
+def rand_pca(rng, d_in, d_out, cls=N.PCANode):
+    return cls(rng.normal(size=d_in), rng.normal(size=(d_in, d_out)) / np.sqrt(d_in))
+
+
+def rand_sfa(rng, d_in, d_out, cls=N.SFANode):
+    return cls(rng.normal(size=d_in) * 0.1, rng.normal(size=(d_in, d_out)) / np.sqrt(d_in))
+
+
+def overlapping_net(seed=0, funcs=None):
+    """8x8 input, 4x4 fields with stride 2 (overlap), then a 3-node merge with overlap; exercises
+    switchboards that reuse inputs, uneven node sizes and sel_exp."""
+    rng = np.random.default_rng(seed)
+    funcs = funcs or [N.identity, N.unsigned_08expo, N.sel_exp(3, N.signed_08expo)]
+    sb0 = N.Rectangular2dSwitchboard((8, 8), (4, 4), (2, 2), 1)          # 3x3 = 9 nodes of 16 inputs
+    l0 = []
+    for k in range(9):
+        p = 5 + (k % 3)                                                    # uneven PCA widths 5..7
+        ex = N.GeneralExpansionNode(funcs, p)
+        l0.append(N.FlowNode([rand_pca(rng, 16, p, N.WhiteningNode), ex, rand_sfa(rng, ex.output_dim, 6)]))
+    sb1 = N.Rectangular2dSwitchboard((3, 3), (2, 2), (1, 1), 6)           # 2x2 = 4 nodes of 24 inputs, overlapping
+    l1 = []
+    for k in range(4):
+        ex = N.GeneralExpansionNode(funcs, 9)
+        l1.append(N.FlowNode([rand_pca(rng, 24, 9), ex, rand_sfa(rng, ex.output_dim, 18 + k, N.GSFANode)]))
+    rng2 = np.random.default_rng(seed + 1)
+    conn = rng2.permutation(sum(18 + k for k in range(4)))[:40]            # irregular switchboard: permuted subset
+    sb2 = N.PInvSwitchboard(sum(18 + k for k in range(4)), conn)
+    ex = N.GeneralExpansionNode(funcs, 12)
+    top = N.Layer([N.FlowNode([rand_pca(rng, 40, 12), ex, rand_sfa(rng, ex.output_dim, 20)])])
+    return [sb0, N.Layer(l0), sb1, N.Layer(l1), sb2, top]
+
+
+def linear_net(seed=0):
+    """Linear PCA network (the reference's age net is 'linearPCANetworkU11L'):
+    Pipelines/Pipeline_experimental.txt:64) with a CloneLayer and consecutive affines that fold."""
+    rng = np.random.default_rng(seed)
+    sb0 = N.Rectangular2dSwitchboard((8, 8), (4, 4), (4, 4), 1)
+    l0 = N.CloneLayer(rand_pca(rng, 16, 7), 4)
+    sb1 = N.Rectangular2dSwitchboard((2, 2), (2, 2), (2, 2), 7)
+    l1 = N.Layer([N.FlowNode([rand_pca(rng, 28, 12), rand_sfa(rng, 12, 9)])])
+    return [sb0, l0, sb1, l1]
+
+
+def product_net(seed=0):
+    """Expansions with cross-column products (QT, pair products), HeadNode, CutoffNode: generic plan."""
+    rng = np.random.default_rng(seed)
+    funcs = [N.identity, N.QT, N.pair_prodsadj1_ex, N.sel_exp(4, N.pair_prodsadj2_ex)]
+    sb0 = N.Rectangular2dSwitchboard((8, 8), (4, 4), (4, 4), 1)
+    l0 = []
+    for _ in range(4):
+        ex = N.GeneralExpansionNode(funcs, 5)
+        l0.append(N.FlowNode([rand_pca(rng, 16, 5), ex, N.CutoffNode(ex.output_dim, -3.0, 3.0),
+                              rand_sfa(rng, ex.output_dim, 8), N.HeadNode(8, 6)]))
+    return [sb0, N.Layer(l0), N.IdentityNode(24), rand_pca(rng, 24, 10)]

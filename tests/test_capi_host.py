@@ -1,0 +1,135 @@
+"""CPU: the C-ABI library loads, exports every symbol include/higsfa.h declares, parses and plans
+flows on the host, rejects malformed blobs, and fails loudly without a GPU (no compute calls)."""
+import ctypes as C
+import os
+import re
+import struct
+
+import numpy as np
+import pytest
+
+from pyfaceanalysis_amd import _capi, blob, synth
+from pyfaceanalysis_amd import nodes as N
+from pyfaceanalysis_amd.flow import Flow
+from tests import helpers
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _load(lib, data, flags=0):
+    h = C.c_void_p()
+    buf = (C.c_char * len(data)).from_buffer_copy(data)
+    rc = lib.hg_flow_load(buf, len(data), flags, C.byref(h))
+    return rc, h
+
+
+def test_header_symbols_exported(native_lib):
+    text = open(os.path.join(ROOT, "include", "higsfa.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(hg_[a-z_0-9]+)\s*\(", text)))
+    assert len(declared) >= 19
+    for name in declared:
+        assert hasattr(native_lib, name), "libhigsfa.so does not export %s" % name
+    assert set(declared) == set(_capi.EXPORTED_SYMBOLS)
+    assert native_lib.hg_version() == 100
+
+
+def test_blob_roundtrip_is_stable():
+    for maker in (helpers.overlapping_net, helpers.linear_net, helpers.product_net):
+        nodes = maker(1)
+        b1 = blob.flow_to_blob(nodes)
+        b2 = blob.flow_to_blob(blob.blob_to_flow(b1))
+        assert b1 == b2 and len(b1) % 8 == 0
+
+
+def test_plans(native_lib, nets):
+    inf, desc = Flow(nets("T5L-16")).host_plan()
+    assert inf.plan_kind == _capi.HG_PLAN_FUSED and inf.input_dim == 256 and inf.output_dim == 10
+    assert inf.flops_per_row == synth.flops_per_row(nets("T5L-16")) and inf.padded_flops_per_row >= inf.flops_per_row
+    assert Flow(nets("T5L-16", layout="separate")).host_plan()[0].plan_kind == _capi.HG_PLAN_FUSED
+    assert Flow(helpers.overlapping_net()).host_plan()[0].plan_kind == _capi.HG_PLAN_FUSED
+    assert Flow(helpers.linear_net()).host_plan()[0].plan_kind == _capi.HG_PLAN_FUSED
+    inf, desc = Flow(nets("T5L-16", node_kind="igsfa")).host_plan()
+    assert inf.plan_kind == _capi.HG_PLAN_GENERIC and "iGSFA" in desc
+    inf, desc = Flow(helpers.product_net()).host_plan()
+    assert inf.plan_kind == _capi.HG_PLAN_GENERIC and "fused plan not used" in desc
+    assert Flow(nets("T5L-16"), force_generic=True).host_plan()[0].plan_kind == _capi.HG_PLAN_GENERIC
+
+
+def test_u11l_128_plan(native_lib, nets):
+    inf, desc = Flow(nets("U11L-128")).host_plan()
+    assert inf.plan_kind == _capi.HG_PLAN_FUSED and inf.n_stages == 12
+    assert inf.flops_per_row == 11017088 and inf.padded_flops_per_row == 13731840
+    assert inf.input_dim == 16384 and inf.output_dim == 60 and inf.n_top_nodes == 22
+
+
+def test_malformed_blobs_are_rejected(native_lib):
+    good = blob.flow_to_blob(helpers.overlapping_net())
+    rc, h = _load(native_lib, good)
+    assert rc == 0
+    native_lib.hg_flow_free(h)
+    bad = [good[:10], good[:40], good[:len(good) // 2], good[:-8], b"XXXXXXXX" + good[8:],
+           good[:8] + struct.pack("<I", 9) + good[12:], good + b"\0" * 8]
+    # corrupt the first switchboard connection (header 24 + flow head 16 + node head 16 = offset 56)
+    ba = bytearray(good)
+    struct.pack_into("<i", ba, 56, 10 ** 6)
+    bad.append(bytes(ba))
+    ba = bytearray(good)
+    struct.pack_into("<I", ba, 24 + 4, 77)      # flow input_dim no longer matches the first node
+    bad.append(bytes(ba))
+    rng = np.random.default_rng(0)
+    for _ in range(40):                         # random single-word corruptions must never crash
+        ba = bytearray(good)
+        off = int(rng.integers(6, 200)) * 4
+        struct.pack_into("<I", ba, off, int(rng.integers(0, 2 ** 32)))
+        bad.append(bytes(ba))
+    n_rejected = 0
+    for b in bad:
+        rc, h = _load(native_lib, b)
+        if rc == 0:
+            native_lib.hg_flow_free(h)          # a corrupted float payload is still a valid flow
+        else:
+            n_rejected += 1
+            assert rc in (_capi.HG_ERR_FORMAT, _capi.HG_ERR_DIM, _capi.HG_ERR_ARG)
+            assert len(native_lib.hg_last_error()) > 0
+    assert n_rejected >= 9
+    rc = native_lib.hg_flow_load(None, 0, 0, C.byref(C.c_void_p()))
+    assert rc == _capi.HG_ERR_ARG
+
+
+def test_python_blob_validation():
+    with pytest.raises(ValueError):
+        blob.flow_to_blob([])
+    with pytest.raises(ValueError):
+        blob.flow_to_blob([N.IdentityNode(4), N.IdentityNode(5)])
+    with pytest.raises(ValueError):
+        N.Switchboard(4, [0, 4])
+    with pytest.raises(ValueError):
+        blob.blob_to_flow(b"nonsense" * 10)
+
+
+def test_flow_container_protocol(nets):
+    nodes = nets("T5L-16")
+    f = Flow(nodes)
+    assert len(f) == 10 and f[0] is nodes[0] and f.input_dim == 256 and f.output_dim == 10
+    assert isinstance(f[:4], Flow) and len(f[:4]) == 4 and [n for n in f] == nodes
+    with pytest.raises(_capi.NodeException):
+        f.execute(np.zeros((3, 255)))            # dimension check happens before any device work
+    with pytest.raises(_capi.NodeException):
+        f.execute(np.zeros(256))
+    with pytest.raises(ValueError):
+        Flow([])
+
+
+def test_no_gpu_means_loud_failure(native_lib, nets):
+    cnt = C.c_int(-1)
+    assert native_lib.hg_device_count(C.byref(cnt)) == 0
+    if cnt.value > 0:
+        pytest.skip("a GPU is visible; the no-device path cannot be exercised")
+    f = Flow(nets("T3L-8"))
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        f.execute(np.zeros((2, 64)))
+    from pyfaceanalysis_amd.classifier import GaussianClassifier
+    g = GaussianClassifier(np.zeros((2, 3)), np.stack([np.eye(3)] * 2), np.ones(2), np.ones(2) / 2, avg_labels=[0.0, 1.0])
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        g.regression(np.zeros((2, 3)))

@@ -1,14 +1,22 @@
 """GPU parity: HIP path (through the C ABI) vs the float64 oracle on identical batches.
 Tolerance (BASELINE.json north_star): max|y - ref| / max|ref| <= 1e-4 in fp32."""
+import glob
+import os
+
 import numpy as np
 import pytest
 
 from oracle import mdp_restate as oracle
-from pyfaceanalysis_amd import synth
+from oracle import ref_c
+from pyfaceanalysis_amd import _capi, synth
+from pyfaceanalysis_amd.blob import blob_to_flow
+from pyfaceanalysis_amd.classifier import GaussianClassifier
 from pyfaceanalysis_amd.flow import Flow
+from tests import helpers
 
 pytestmark = pytest.mark.gpu
-TOL = 1e-4
+TOL = 1e-4            # relative to max|ref| (north_star)
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
 def rel_err(y, ref):
@@ -32,6 +40,29 @@ def test_small_nets_match_oracle(native_lib, nets, preset, kw, force_generic):
 
 
 @pytest.mark.parametrize("force_generic", [True, False])
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "flow_*.npz"))))
+def test_golden_fixtures(native_lib, path, force_generic):
+    """Committed fixtures (uint8 sub-images in, float64 features out)."""
+    g = np.load(path)
+    flow = Flow.from_blob(g["blob"].tobytes(), force_generic=force_generic)
+    assert rel_err(flow.execute(g["x"]), g["y"]) <= TOL
+    flow.close()
+
+
+@pytest.mark.parametrize("force_generic", [True, False])
+@pytest.mark.parametrize("maker", [helpers.overlapping_net, helpers.linear_net, helpers.product_net])
+def test_awkward_structures(native_lib, maker, force_generic):
+    """Overlapping fields, irregular switchboards, uneven node widths, sel_exp, clone layers, folded
+    affines, product expansions / Head / Cutoff (generic plan)."""
+    nodes = maker(5)
+    x = np.random.default_rng(2).normal(size=(53, nodes[0].input_dim)) * 1.5
+    ref = oracle.execute_flow(nodes, x)
+    flow = Flow(nodes, force_generic=force_generic)
+    assert rel_err(flow.execute(x), ref) <= TOL
+    flow.close()
+
+
+@pytest.mark.parametrize("force_generic", [True, False])
 def test_u11l_128_matches_oracle(native_lib, nets, force_generic):
     """BASELINE.json configs[0]: the 11-layer net on 256 sub-images of 128x128."""
     nodes = nets("U11L-128")
@@ -44,3 +75,109 @@ def test_u11l_128_matches_oracle(native_lib, nets, force_generic):
     print("U11L-128 generic=%s max|d|/max|ref| = %.3e; worst of first 20 cols %.3e" % (force_generic, err, percol.max()))
     assert err <= TOL
     flow.close()
+
+
+def test_u11l_64_matches_oracle(native_lib, nets):
+    """The shipped pipelines feed 64x64 sub-images (Pipelines/Pipeline_experimental.txt:2)."""
+    nodes = nets("U11L-64")
+    x = synth.make_subimages(100, 64, dtype=np.float64)
+    ref = oracle.execute_flow(nodes, x)
+    flow = Flow(nodes)
+    assert flow.info().plan_kind == _capi.HG_PLAN_FUSED
+    assert rel_err(flow.execute(x), ref) <= TOL
+    flow.close()
+
+
+def test_input_dtypes_layouts_and_edges(native_lib, nets):
+    nodes = nets("T5L-16")
+    flow = Flow(nodes)
+    xi = synth.make_subimages(50, 16, dtype=np.uint8)
+    ref = oracle.execute_flow(nodes, xi)
+    y8 = flow.execute(xi)
+    assert rel_err(y8, ref) <= TOL
+    # integer pixels are exact in every input type -> identical device arithmetic
+    assert np.array_equal(y8, flow.execute(xi.astype(np.float32)))
+    assert np.array_equal(y8, flow.execute(xi.astype(np.float64)))
+    assert np.array_equal(y8, flow.execute(np.asfortranarray(xi.astype(np.float64))))      # F order
+    wide = np.zeros((50, 300), dtype=np.float32)
+    wide[:, 7:263] = xi
+    assert np.array_equal(y8, flow.execute(wide[:, 7:263]))                                # strided rows, unaligned
+    assert np.array_equal(y8, flow.execute(xi.astype(np.int32)))                           # other dtypes are cast
+    # batch-size edges: the reference calls with N = 1..728 (SURVEY.md §6), guards N == 0 itself
+    for n in (0, 1, 15, 16, 17, 33):
+        yn = flow.execute(xi[:n])
+        assert yn.shape == (n, 10)
+        assert np.array_equal(yn, y8[:n])                   # a row's result never depends on its neighbours
+    # first-k columns (the caller consumes sl[:, 0:reg_num_signals], FaceDetectUpdated.py:719)
+    assert np.array_equal(flow.execute(xi, n_cols=4), y8[:, :4])
+    f32 = Flow(nodes, output_dtype=np.float32)
+    y32 = f32.execute(xi)
+    assert y32.dtype == np.float32 and np.array_equal(y32.astype(np.float64), y8)
+    with pytest.raises(_capi.NodeException):
+        flow.execute(np.zeros((4, 255)))
+    flow.close()
+    f32.close()
+
+
+def test_nodenr_and_benchmark_kwarg(native_lib, nets):
+    nodes = nets("T5L-16")
+    flow = Flow(nodes)
+    x = synth.make_subimages(20, 16, dtype=np.float64)
+    for nodenr in (0, 1, 3, 9):
+        ref = oracle.execute_flow(nodes, x, nodenr=nodenr)
+        assert rel_err(flow.execute(x, nodenr=nodenr), ref) <= TOL
+
+    class Bench(object):                      # interface of benchmarking.Benchmark (benchmarking.py:39-58)
+        enabled = True
+        default_reference = "networks"
+
+        def __init__(self):
+            self.tasks = []
+
+        def add_task_ellapsed(self, label, secs, reference=None):
+            self.tasks.append((reference, label, secs))
+
+    b = Bench()
+    flow.execute(x, benchmark=b)
+    assert len(b.tasks) == flow.info().n_stages and all(t[0] == "networks" and t[2] >= 0 for t in b.tasks)
+    flow.close()
+
+
+def test_full_size_properties(native_lib, nets):
+    """BASELINE.json configs[1] size (4096 x 128x128), where the oracle is too slow to be the only check:
+    (1) fused and generic plans (independent HIP implementations) agree; (2) determinism: two runs are
+    bit-identical; (3) row-permutation equivariance, bit-exact: a sub-image's features do not depend on
+    where in the batch it sits; (4) a slice is checked against the oracle."""
+    nodes = nets("U11L-128")
+    n = 4096
+    x = synth.make_subimages(n, 128, dtype=np.uint8)
+    fused, generic = Flow(nodes, output_dtype=np.float32), Flow(nodes, output_dtype=np.float32, force_generic=True)
+    y = fused.execute(x, n_cols=20)
+    assert np.array_equal(y, fused.execute(x, n_cols=20))
+    yg = generic.execute(x, n_cols=20)
+    assert rel_err(y, yg.astype(np.float64)) <= TOL
+    perm = np.random.default_rng(0).permutation(n)
+    assert np.array_equal(fused.execute(x[perm], n_cols=20), y[perm])
+    idx = np.arange(0, n, 64)
+    ref = oracle.execute_flow(nodes, x[idx])[:, :20]
+    assert rel_err(y[idx], ref) <= TOL
+    fused.close()
+    generic.close()
+
+
+def test_gaussian_regression(native_lib):
+    """hg_gauss_regression on the parameters of three of the reference's own classifier files."""
+    g = np.load(os.path.join(GOLD, "classifiers.npz"))
+    for i in range(3):
+        clf = GaussianClassifier(g["c%d_means" % i], g["c%d_inv_covs" % i], g["c%d_sqrt_def_covs" % i], g["c%d_p" % i],
+                                 avg_labels=g["c%d_avg_labels" % i])
+        x = g["c%d_x" % i]
+        reg, std = clf.regression(x, estimate_std=True)
+        assert np.allclose(reg, g["c%d_reg" % i], rtol=1e-9, atol=1e-9 * np.abs(g["c%d_reg" % i]).max())
+        assert np.allclose(std, g["c%d_std" % i], rtol=1e-6, atol=1e-7 * (1 + np.abs(g["c%d_std" % i]).max()))
+        reg32 = clf.regression(x.astype(np.float32))
+        ref32 = ref_c.gauss_regression(x.astype(np.float32).astype(np.float64), clf.means, clf.inv_covs, clf._sqrt_def_covs,
+                                       clf.p, clf.avg_labels, want_std=False)
+        assert np.allclose(reg32, ref32, rtol=1e-9, atol=1e-9 * np.abs(ref32).max())
+        assert clf.regression(x[:0]).shape == (0,)
+        clf.close()
