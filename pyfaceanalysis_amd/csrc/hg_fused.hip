@@ -239,7 +239,7 @@ bool build_stages(const TNode& root, std::vector<FStage>& stages, std::string& w
 constexpr int kMaxFuncs = 8;
 
 struct DChunk {   // stage 0: a group of consecutive nodes whose input columns share one LDS tile
-    int32_t node_begin, node_count, run_begin, run_count, n_cols, piece_begin, pad0, pad1;
+    int32_t node_begin, node_count, run_begin, run_count, n_cols, piece_begin, n_pieces, pad1;
 };
 struct DRun {
     int32_t start, len, lds_off, pad;
@@ -253,14 +253,14 @@ struct StageParams {
     f32x4* out;
     int32_t n_nodes, kb1, nf, has_exp;
     int32_t node_blocks, bias_floats, n_tiles, nb_in, nb_out, mto;
-    int32_t nodes_per_group, nodes_per_wg, n_chunks, tile_groups;
+    int32_t nodes_per_group, nodes_per_wg, n_chunks, tile_groups, tile_parts;
     int32_t func[kMaxFuncs];
     float expo[kMaxFuncs];
     uint8_t nk2[kMaxMT][kMaxFuncs];
     // stage 0
     const DChunk* chunks;
     const DRun* runs;
-    const int32_t* piece_col;  // per chunk piece (4 columns) -> first source column
+    const int2* piece_col;     // per chunk piece (4 columns) -> {first source column, LDS word offset}
     const int32_t* koff;       // [node*kb1 + kb][g][r] LDS word offsets
     const float* kmean;        // same shape: means subtracted by the loader
     const void* x;
@@ -358,12 +358,8 @@ __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
     // XCD-aware decode: blocks b, b+8, ... share an XCD (and its L2); give each XCD whole node
     // chunks so a chunk's weights are fetched into one L2 only.
     const int xcd = blockIdx.x & 7, kq = blockIdx.x >> 3;
-    const int chunk = xcd + 8 * (kq / P.tile_groups), grp = kq % P.tile_groups;
+    const int chunk = xcd + 8 * (kq / P.tile_parts), part = kq % P.tile_parts;
     if (chunk >= P.n_chunks) return;
-    int tile[T];
-#pragma unroll
-    for (int t = 0; t < T; ++t) tile[t] = (grp * nw + wave) * T + t;
-    const bool active = tile[0] < P.n_tiles;
     const int n_begin = chunk * P.nodes_per_wg;
     const int n_end = min(n_begin + P.nodes_per_wg, P.n_nodes);
     const int npg = P.nodes_per_group;
@@ -391,45 +387,52 @@ __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
             for (int k = tid; k < gn * P.kb1; k += nthr) stab[k] = tsrc[k];
         }
         __syncthreads();
-        if (!active) continue;
-        for (int ln = 0; ln < gn; ++ln) {
-            const f32x4* wA1 = smem + (size_t)ln * P.node_blocks * 64 + lane;
-            const f32x4* wA2 = wA1 + P.kb1 * MT1 * 64;
-            const float* b1 = sb + ln * P.bias_floats;
-            const int2* kt = stab + ln * P.kb1;
-            f32x4 z[MT1][T];
+        // the workgroup keeps this node group's weights in LDS and sweeps its share of the batch:
+        // tile groups part, part + tile_parts, ...  (no barrier inside: waves run free)
+        for (int grp = part; grp < P.tile_groups; grp += P.tile_parts) {
+            int tile[T];
 #pragma unroll
-            for (int mt = 0; mt < MT1; ++mt) {
-                f32x4 bb = *(const f32x4*)(b1 + mt * 16 + g * 4);
-#pragma unroll
-                for (int t = 0; t < T; ++t) z[mt][t] = bb;
-            }
+            for (int t = 0; t < T; ++t) tile[t] = (grp * nw + wave) * T + t;
+            if (tile[0] >= P.n_tiles) break;
             size_t trow[T];
 #pragma unroll
             for (int t = 0; t < T; ++t) trow[t] = (size_t)(tile[t] < P.n_tiles ? tile[t] : tile[0]) * P.nb_in;
-            int2 kb = kt[0];
-            int src_blk = __builtin_amdgcn_readfirstlane(kb.x);
-            int nk = __builtin_amdgcn_readfirstlane(kb.y);
-            f32x4 bf[T], bfn[T];
+            for (int ln = 0; ln < gn; ++ln) {
+                const f32x4* wA1 = smem + (size_t)ln * P.node_blocks * 64 + lane;
+                const f32x4* wA2 = wA1 + P.kb1 * MT1 * 64;
+                const float* b1 = sb + ln * P.bias_floats;
+                const int2* kt = stab + ln * P.kb1;
+                f32x4 z[MT1][T];
 #pragma unroll
-            for (int t = 0; t < T; ++t) bf[t] = P.in[(trow[t] + src_blk) * 64 + lane];
-            for (int kbi = 0; kbi < P.kb1; ++kbi) {
-                // unconditional prefetch of the next K-block's activation fragments (the last
-                // iteration re-reads its own block) so the wait below can be a counted vmcnt
-                const int2 kbn = kt[kbi + 1 < P.kb1 ? kbi + 1 : kbi];
-                const int sbn = __builtin_amdgcn_readfirstlane(kbn.x);
-                const int nkn = __builtin_amdgcn_readfirstlane(kbn.y);
+                for (int mt = 0; mt < MT1; ++mt) {
+                    f32x4 bb = *(const f32x4*)(b1 + mt * 16 + g * 4);
 #pragma unroll
-                for (int t = 0; t < T; ++t) bfn[t] = P.in[(trow[t] + sbn) * 64 + lane];
-                f32x4 a[MT1];
+                    for (int t = 0; t < T; ++t) z[mt][t] = bb;
+                }
+                int2 kb = kt[0];
+                int src_blk = __builtin_amdgcn_readfirstlane(kb.x);
+                int nk = __builtin_amdgcn_readfirstlane(kb.y);
+                f32x4 bf[T], bfn[T];
 #pragma unroll
-                for (int mt = 0; mt < MT1; ++mt) a[mt] = wA1[(kbi * MT1 + mt) * 64];
-                mfma_block<MT1, T>(a, bf, z, nk);
+                for (int t = 0; t < T; ++t) bf[t] = P.in[(trow[t] + src_blk) * 64 + lane];
+                for (int kbi = 0; kbi < P.kb1; ++kbi) {
+                    // unconditional prefetch of the next K-block's activation fragments (the last
+                    // iteration re-reads its own block) so the wait below can be a counted vmcnt
+                    const int2 kbn = kt[kbi + 1 < P.kb1 ? kbi + 1 : kbi];
+                    const int sbn = __builtin_amdgcn_readfirstlane(kbn.x);
+                    const int nkn = __builtin_amdgcn_readfirstlane(kbn.y);
 #pragma unroll
-                for (int t = 0; t < T; ++t) bf[t] = bfn[t];
-                nk = nkn;
+                    for (int t = 0; t < T; ++t) bfn[t] = P.in[(trow[t] + sbn) * 64 + lane];
+                    f32x4 a[MT1];
+#pragma unroll
+                    for (int mt = 0; mt < MT1; ++mt) a[mt] = wA1[(kbi * MT1 + mt) * 64];
+                    mfma_block<MT1, T>(a, bf, z, nk);
+#pragma unroll
+                    for (int t = 0; t < T; ++t) bf[t] = bfn[t];
+                    nk = nkn;
+                }
+                node_tail<MT1, MT2, T>(P, wA2, b1 + MT1 * 16, (g0 + ln) * P.mto, z, tile, lane);
             }
-            node_tail<MT1, MT2, T>(P, wA2, b1 + MT1 * 16, (g0 + ln) * P.mto, z, tile, lane);
         }
     }
 }
@@ -468,10 +471,10 @@ template <> struct Vec4Load<double> {
 };
 
 template <int MT1, int MT2, int T, typename XT>
-__global__ void __launch_bounds__(256) k_stage0(StageParams P) {
+__global__ void __launch_bounds__(512) k_stage0(StageParams P) {
     extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
     float* lds = (float*)smem;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, j = lane & 15;
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nthr >> 6, g = lane >> 4, j = lane & 15;
     const int ci = blockIdx.x % P.n_chunks, grp = blockIdx.x / P.n_chunks;
     const DChunk ck = P.chunks[ci];
     int tile[T];
@@ -480,36 +483,36 @@ __global__ void __launch_bounds__(256) k_stage0(StageParams P) {
     const XT* x = (const XT*)P.x;
     const int stride = P.lds_stride;
     if (P.vec4) {
-        const int pps = ck.n_cols >> 2;          // 16-byte pieces per sub-image
+        const int pps = ck.n_pieces;             // 16-byte pieces per sub-image
         const int total = T * 16 * pps;
-        const DRun r0 = P.runs[ck.run_begin];
-        for (int base = 0; base < total; base += 256 * 4) {
-            f32x4 v[4];
-            int dsto[4];
+        constexpr int NB = 8;                    // loads in flight per thread
+        for (int base = 0; base < total; base += nthr * NB) {
+            f32x4 v[NB];
+            int dsto[NB];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int idx = base + k * 256 + tid;
+            for (int k = 0; k < NB; ++k) {
+                const int idx = base + k * nthr + tid;
                 dsto[k] = -1;
                 if (idx < total) {
                     const int sj = idx / pps, pc = idx - sj * pps;
-                    const int col = ck.run_count == 1 ? r0.start + 4 * pc : P.piece_col[ck.piece_begin + pc];
+                    const int2 pcol = P.piece_col[ck.piece_begin + pc];   // {source column, LDS word offset}
                     const int tl = tile[0] + sj / 16;
                     const int64_t row = (int64_t)tl * 16 + (sj & 15);
-                    dsto[k] = sj * stride + 4 * pc;
+                    dsto[k] = sj * stride + pcol.y;
                     if (tl < P.n_tiles && row < P.n_rows)
-                        v[k] = Vec4Load<XT>::ld(x + row * P.ldx + col);
+                        v[k] = Vec4Load<XT>::ld(x + row * P.ldx + pcol.x);
                     else
                         v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < NB; ++k)
                 if (dsto[k] >= 0) *(f32x4*)(lds + dsto[k]) = v[k];
         }
         if (tid < T * 16) lds[tid * stride + stride - 1] = 0.f;
     } else {
         for (int t = 0; t < T; ++t)
-            for (int jj = wave; jj < 16; jj += 4) {
+            for (int jj = wave; jj < 16; jj += nw) {
                 const int64_t row = (int64_t)tile[t] * 16 + jj;
                 float* dst = lds + (t * 16 + jj) * stride;
                 const bool ok = tile[t] < P.n_tiles && row < P.n_rows;
@@ -522,7 +525,7 @@ __global__ void __launch_bounds__(256) k_stage0(StageParams P) {
             }
     }
     __syncthreads();
-    for (int ni = ck.node_begin + wave; ni < ck.node_begin + ck.node_count; ni += 4) {
+    for (int ni = ck.node_begin + wave; ni < ck.node_begin + ck.node_count; ni += nw) {
         const f32x4* wA1 = P.afrag + (size_t)ni * P.node_blocks * 64 + lane;
         const f32x4* wA2 = wA1 + P.kb1 * MT1 * 64;
         const float* b1 = P.bias + (size_t)ni * P.bias_floats;
@@ -632,7 +635,7 @@ StageFn pick_stage0(int mt1, int mt2, int T, int x_dtype) {
 // ---- the executor --------------------------------------------------------------------------------
 inline int q_of_row(int i) { return 4 * (i & 3) + (i >> 2); }  // tile row -> tile-local feature (involution)
 
-constexpr int kStage0ChunkCols = 128;   // columns of one sub-image staged per chunk (T = 4 tiles -> ~33 KiB LDS)
+constexpr int kStage0ChunkCols = 256;   // columns of one sub-image staged per chunk (T = 4 tiles -> ~66 KiB LDS)
 constexpr int kWeightLdsKiB = 64;       // target size of a node group's weights in LDS
 
 struct HostStage {
@@ -867,7 +870,8 @@ public:
             if (!s.chunks.empty()) {
                 s.d_chunks.upload(s.chunks.data(), s.chunks.size() * sizeof(DChunk));
                 s.d_runs.upload(s.runs.data(), s.runs.size() * sizeof(DRun));
-                s.d_piece.upload(s.piece_col.data(), std::max<size_t>(s.piece_col.size(), 1) * 4);
+                s.piece_col.resize(std::max<size_t>(s.piece_col.size(), 2));
+                s.d_piece.upload(s.piece_col.data(), s.piece_col.size() * 4);
                 s.d_koff.upload(s.koff.data(), s.koff.size() * 4);
                 s.d_kmean.upload(s.kmean.data(), s.kmean.size() * 4);
             }
@@ -917,7 +921,7 @@ public:
             if (si == 0) {
                 P.chunks = (const DChunk*)s.d_chunks.p;
                 P.runs = (const DRun*)s.d_runs.p;
-                P.piece_col = (const int32_t*)s.d_piece.p;
+                P.piece_col = (const int2*)s.d_piece.p;
                 P.koff = (const int32_t*)s.d_koff.p;
                 P.kmean = (const float*)s.d_kmean.p;
                 P.x = x;
@@ -937,7 +941,7 @@ public:
                 size_t lds_bytes = (size_t)T * 16 * s.lds_stride * 4;
                 StageFn fn = pick_stage0(s.mt1, s.mt2, T, x_dtype);
                 set_lds_limit(fn, lds_bytes);
-                hipLaunchKernelGGL(fn, (unsigned)blocks, 256, lds_bytes, st, P);
+                hipLaunchKernelGGL(fn, (unsigned)blocks, T == 4 ? 512 : 256, lds_bytes, st, P);
             } else {
                 // node groups sized so a group's weights are ~64 KiB of LDS (always >= 1 node)
                 const int npg = std::max(1, std::min(s.n_nodes, kWeightLdsKiB / std::max(1, s.node_blocks)));
@@ -957,12 +961,27 @@ public:
                 }
                 while (nw * T > std::max(n_tiles, 1) && nw > 1) nw >>= 1;
                 const int tile_groups = (n_tiles + nw * T - 1) / (nw * T);
-                int groups_per_wg = (int)std::max<int64_t>(1, (int64_t)n_groups * tile_groups / 4096);
+                // persistent sweep: each workgroup copies its node group's weights once and walks
+                // tile groups part, part + tile_parts, ...; aim at ~3 workgroups per CU in total
+                // cost(P) = rounds of resident workgroups x (weight copy + tile iterations per workgroup)
+                const int64_t g8 = (int64_t)(n_groups + 7) / 8 * 8;
+                const double capacity = 4096.0 / nw;   // resident workgroups: 256 CUs x 16 waves
+                int tile_parts = 1;
+                double best = 1e300;
+                for (int pp = 1; pp <= tile_groups; ++pp) {
+                    double rounds = std::ceil(g8 * pp / capacity);
+                    double cost = rounds * (0.35 + (double)((tile_groups + pp - 1) / pp));
+                    if (cost < best - 1e-9) {
+                        best = cost;
+                        tile_parts = pp;
+                    }
+                }
                 P.nodes_per_group = npg;
-                P.nodes_per_wg = npg * groups_per_wg;
-                P.n_chunks = (s.n_nodes + P.nodes_per_wg - 1) / P.nodes_per_wg;
+                P.nodes_per_wg = npg;
+                P.n_chunks = n_groups;
                 P.tile_groups = tile_groups;
-                const int64_t blocks = (int64_t)((P.n_chunks + 7) / 8) * 8 * tile_groups;
+                P.tile_parts = tile_parts;
+                const int64_t blocks = (int64_t)((P.n_chunks + 7) / 8) * 8 * tile_parts;
                 if (blocks > 0x7fffffffll) fail(HG_ERR_ARG, "batch too large");
                 size_t lds_bytes = (size_t)npg * s.node_blocks * 1024 + (size_t)npg * s.bias_floats * 4 + (size_t)npg * s.kb1 * 8;
                 StageFn fn = pick_stage(s.mt1, s.mt2, T);
@@ -1036,17 +1055,25 @@ private:
                 cols.swap(c2);
                 ++n1;
             }
-            DChunk ck{ni, n1 - ni, (int)hs.runs.size(), 0, 0, (int)hs.piece_col.size(), 0, 0};
+            DChunk ck{ni, n1 - ni, (int)hs.runs.size(), 0, 0, (int)hs.piece_col.size() / 2, 0, 0};
             std::map<int32_t, int32_t> lds_of;
             int off = 0;
             for (size_t i = 0; i < cols.size();) {
                 size_t k = i + 1;
                 while (k < cols.size() && cols[k] == cols[k - 1] + 1) ++k;
                 const int len = (int)(k - i);
+                // every run starts on a 64-word (256 B = one LDS bank row) boundary: the four lane
+                // groups of a ds_read_b128 then differ only by multiples of the bank row and the 16
+                // sub-images of a group (stride == 4 mod 64) take 16 distinct 16-byte slots
+                off = (off + 63) / 64 * 64;
                 hs.runs.push_back(DRun{cols[i], len, off, 0});
                 if (cols[i] % 4 || len % 4) vec_ok = false;
                 for (size_t m = i; m < k; ++m) lds_of[cols[m]] = off + (int)(m - i);
-                for (int pc = 0; pc + 3 < len; pc += 4) hs.piece_col.push_back(cols[i] + pc);
+                for (int pc = 0; pc + 3 < len; pc += 4) {
+                    hs.piece_col.push_back(cols[i] + pc);
+                    hs.piece_col.push_back(off + pc);
+                    ++ck.n_pieces;
+                }
                 off += len;
                 i = k;
                 ++ck.run_count;
