@@ -26,6 +26,7 @@
 #include <cmath>
 #include <map>
 #include <sstream>
+#include <tuple>
 
 #include "hg_common.hpp"
 
@@ -236,7 +237,7 @@ bool build_stages(const TNode& root, std::vector<FStage>& stages, std::string& w
 // expansion list for all its nodes; missing pieces are zero weights), so all weight / bias
 // addresses are arithmetic on the node index and the only per-node table is the list of source
 // blocks of GEMM 1.
-constexpr int kMaxFuncs = 8;
+constexpr int kMaxFuncs = 4;
 
 struct DChunk {   // stage 0: a group of consecutive nodes whose input columns share one LDS tile
     int32_t node_begin, node_count, run_begin, run_count, n_cols, piece_begin, n_pieces, pad1;
@@ -254,9 +255,9 @@ struct StageParams {
     int32_t n_nodes, kb1, nf, has_exp;
     int32_t node_blocks, bias_floats, n_tiles, nb_in, nb_out, mto;
     int32_t nodes_per_group, nodes_per_wg, n_chunks, tile_groups, tile_parts;
-    int32_t func[kMaxFuncs];
+    uint32_t nk2p[kMaxMT];     // per z tile: 4 bits of k-steps per expansion function
+    uint32_t funcp;            // 4 bits of ExpKind per expansion function
     float expo[kMaxFuncs];
-    uint8_t nk2[kMaxMT][kMaxFuncs];
     // stage 0
     const DChunk* chunks;
     const DRun* runs;
@@ -289,16 +290,37 @@ __device__ __forceinline__ f32x4 apply_func(int func, float expo, f32x4 z) {
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-template <int MT, int T>
-__device__ __forceinline__ void mfma_block(const f32x4 (&a)[MT], const f32x4 (&b)[T], f32x4 (&acc)[MT][T], int nk) {
+// One K-block: acc[mt][t] += A[mt] (16 x 16, four k-steps) * B[t].  `wp` points at the block's first
+// A fragment (+lane); fragments of consecutive m-tiles are 64 f32x4 apart.  With T >= 2 the A
+// fragment is read one m-tile at a time (4 live registers instead of 4*MT): consecutive MFMAs then
+// alternate between T accumulators, which is enough to cover the 40-cycle dependent latency of
+// v_mfma_f32_16x16x4_f32.  With T == 1 all m-tiles are interleaved instead.
+template <int MT, int T, typename WP>
+__device__ __forceinline__ void gemm_block(WP wp, const f32x4 (&b)[T], f32x4 (&acc)[MT][T], int nk) {
+    if constexpr (T >= 2) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-        if (r < nk) {
+        for (int mt = 0; mt < MT; ++mt) {
+            const f32x4 a = wp[mt * 64];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            for (int r = 0; r < 4; ++r)
+                if (r < nk) {
 #pragma unroll
-                for (int t = 0; t < T; ++t) acc[mt][t] = MFMA16(a[mt][r], b[t][r], acc[mt][t]);
+                    for (int t = 0; t < T; ++t) acc[mt][t] = MFMA16(a[r], b[t][r], acc[mt][t]);
+                }
         }
+    } else {
+        f32x4 a[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[mt] = wp[mt * 64];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (r < nk) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int t = 0; t < T; ++t) acc[mt][t] = MFMA16(a[mt][r], b[t][r], acc[mt][t]);
+            }
+    }
 }
 
 // Second half of a node: expansion of the z accumulators in registers, second affine, store.
@@ -323,20 +345,21 @@ __device__ __forceinline__ void node_tail(const StageParams& P, WP wA2, BP b2, i
 #pragma unroll
         for (int t = 0; t < T; ++t) y[mt][t] = bb;
     }
+    const float ex0 = P.expo[0], ex1 = P.expo[1], ex2 = P.expo[2], ex3 = P.expo[3];
+    const uint32_t funcp = P.funcp;
+    const int nf = P.nf;
 #pragma unroll
     for (int mt1 = 0; mt1 < MT1; ++mt1) {
-        for (int fi = 0; fi < P.nf; ++fi) {
-            const int nk = P.nk2[mt1][fi];
+        const uint32_t nkp = P.nk2p[mt1];
+        for (int fi = 0; fi < nf; ++fi) {
+            const int nk = (nkp >> (4 * fi)) & 15;
             if (nk == 0) continue;
-            f32x4 a[MT2];
-#pragma unroll
-            for (int mt = 0; mt < MT2; ++mt) a[mt] = wA2[((mt1 * P.nf + fi) * MT2 + mt) * 64];
             f32x4 e[T];
-            const int fk = P.func[fi];
-            const float ex = P.expo[fi];
+            const int fk = (funcp >> (4 * fi)) & 15;
+            const float ex = fi == 0 ? ex0 : (fi == 1 ? ex1 : (fi == 2 ? ex2 : ex3));
 #pragma unroll
             for (int t = 0; t < T; ++t) e[t] = apply_func(fk, ex, z[mt1][t]);
-            mfma_block<MT2, T>(a, e, y, nk);
+            gemm_block<MT2, T>(wA2 + (mt1 * nf + fi) * MT2 * 64, e, y, nk);
         }
     }
 #pragma unroll
@@ -354,7 +377,8 @@ template <int MT1, int MT2, int T>
 __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
     extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
     const int tid = threadIdx.x, nthr = blockDim.x;
-    const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6, g = lane >> 4;
+    const int lane = tid & 63, nw = nthr >> 6, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps tile/row bookkeeping in SGPRs
     // XCD-aware decode: blocks b, b+8, ... share an XCD (and its L2); give each XCD whole node
     // chunks so a chunk's weights are fetched into one L2 only.
     const int xcd = blockIdx.x & 7, kq = blockIdx.x >> 3;
@@ -387,16 +411,36 @@ __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
             for (int k = tid; k < gn * P.kb1; k += nthr) stab[k] = tsrc[k];
         }
         __syncthreads();
-        // the workgroup keeps this node group's weights in LDS and sweeps its share of the batch:
-        // tile groups part, part + tile_parts, ...  (no barrier inside: waves run free)
+        // The workgroup keeps this node group's weights in LDS and sweeps its share of the batch:
+        // tile groups part, part + tile_parts, ...  (no barrier inside: waves run free).  The
+        // activation fragments form ONE prefetch stream across K-blocks, nodes and tile groups:
+        // while block i is multiplied, block i+1 — possibly the first block of the next node or of
+        // the next tile group — is already in flight, so no visit starts with an exposed load.
+        int tile[T];
+        uint32_t trow[T], trow_nx[T];   // first block of the tile's row in the input activation
+#pragma unroll
+        for (int t = 0; t < T; ++t) tile[t] = (part * nw + wave) * T + t;
+        if (tile[0] >= P.n_tiles) continue;
+#pragma unroll
+        for (int t = 0; t < T; ++t) trow[t] = (uint32_t)(tile[t] < P.n_tiles ? tile[t] : tile[0]) * (uint32_t)P.nb_in;
+        f32x4 bf[T], bfn[T];
+        int nk;
+        {
+            const int2 kb = stab[0];
+            const int sb0 = __builtin_amdgcn_readfirstlane(kb.x);
+            nk = __builtin_amdgcn_readfirstlane(kb.y);
+#pragma unroll
+            for (int t = 0; t < T; ++t) bf[t] = P.in[(size_t)(trow[t] + sb0) * 64 + lane];
+        }
         for (int grp = part; grp < P.tile_groups; grp += P.tile_parts) {
-            int tile[T];
+            // rows of the tile group after this one (or this one again when it is the last)
+            const int tn0 = ((grp + P.tile_parts) * nw + wave) * T;
+            const bool has_next = grp + P.tile_parts < P.tile_groups && tn0 < P.n_tiles;
 #pragma unroll
-            for (int t = 0; t < T; ++t) tile[t] = (grp * nw + wave) * T + t;
-            if (tile[0] >= P.n_tiles) break;
-            size_t trow[T];
-#pragma unroll
-            for (int t = 0; t < T; ++t) trow[t] = (size_t)(tile[t] < P.n_tiles ? tile[t] : tile[0]) * P.nb_in;
+            for (int t = 0; t < T; ++t) {
+                const int tn = tn0 + t;
+                trow_nx[t] = has_next ? (uint32_t)(tn < P.n_tiles ? tn : tn0) * (uint32_t)P.nb_in : trow[t];
+            }
             for (int ln = 0; ln < gn; ++ln) {
                 const f32x4* wA1 = smem + (size_t)ln * P.node_blocks * 64 + lane;
                 const f32x4* wA2 = wA1 + P.kb1 * MT1 * 64;
@@ -409,29 +453,26 @@ __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
 #pragma unroll
                     for (int t = 0; t < T; ++t) z[mt][t] = bb;
                 }
-                int2 kb = kt[0];
-                int src_blk = __builtin_amdgcn_readfirstlane(kb.x);
-                int nk = __builtin_amdgcn_readfirstlane(kb.y);
-                f32x4 bf[T], bfn[T];
-#pragma unroll
-                for (int t = 0; t < T; ++t) bf[t] = P.in[(trow[t] + src_blk) * 64 + lane];
                 for (int kbi = 0; kbi < P.kb1; ++kbi) {
-                    // unconditional prefetch of the next K-block's activation fragments (the last
-                    // iteration re-reads its own block) so the wait below can be a counted vmcnt
-                    const int2 kbn = kt[kbi + 1 < P.kb1 ? kbi + 1 : kbi];
+                    const bool in_node = kbi + 1 < P.kb1;
+                    const bool in_group = in_node || ln + 1 < gn;
+                    const int2 kbn = in_node ? kt[kbi + 1] : (ln + 1 < gn ? kt[P.kb1] : stab[0]);
                     const int sbn = __builtin_amdgcn_readfirstlane(kbn.x);
                     const int nkn = __builtin_amdgcn_readfirstlane(kbn.y);
 #pragma unroll
-                    for (int t = 0; t < T; ++t) bfn[t] = P.in[(trow[t] + sbn) * 64 + lane];
-                    f32x4 a[MT1];
-#pragma unroll
-                    for (int mt = 0; mt < MT1; ++mt) a[mt] = wA1[(kbi * MT1 + mt) * 64];
-                    mfma_block<MT1, T>(a, bf, z, nk);
+                    for (int t = 0; t < T; ++t) bfn[t] = P.in[(size_t)((in_group ? trow[t] : trow_nx[t]) + sbn) * 64 + lane];
+                    gemm_block<MT1, T>(wA1 + kbi * MT1 * 64, bf, z, nk);
 #pragma unroll
                     for (int t = 0; t < T; ++t) bf[t] = bfn[t];
                     nk = nkn;
                 }
                 node_tail<MT1, MT2, T>(P, wA2, b1 + MT1 * 16, (g0 + ln) * P.mto, z, tile, lane);
+            }
+            if (!has_next) break;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                tile[t] = tn0 + t;
+                trow[t] = trow_nx[t];
             }
         }
     }
@@ -540,9 +581,6 @@ __global__ void __launch_bounds__(512) k_stage0(StageParams P) {
             const size_t ent = ((size_t)ni * P.kb1 + kbi) * 16 + g * 4;
             const i32x4 off = *(const i32x4*)(P.koff + ent);
             const f32x4 mu = *(const f32x4*)(P.kmean + ent);
-            f32x4 a[MT1];
-#pragma unroll
-            for (int mt = 0; mt < MT1; ++mt) a[mt] = wA1[(kbi * MT1 + mt) * 64];
             f32x4 bf[T];
             if (P.contig4) {
 #pragma unroll
@@ -555,7 +593,7 @@ __global__ void __launch_bounds__(512) k_stage0(StageParams P) {
                     for (int r = 0; r < 4; ++r) bf[t][r] = base[off[r]] - mu[r];
                 }
             }
-            mfma_block<MT1, T>(a, bf, z, kbi == P.kb1 - 1 ? P.nk_last : 4);
+            gemm_block<MT1, T>(wA1 + kbi * MT1 * 64, bf, z, kbi == P.kb1 - 1 ? P.nk_last : 4);
         }
         node_tail<MT1, MT2, T>(P, wA2, b1 + MT1 * 16, ni * P.mto, z, tile, lane);
     }
@@ -914,10 +952,10 @@ public:
             P.nb_out = s.nb_out;
             P.mto = s.mto;
             for (int fi = 0; fi < s.nf; ++fi) {
-                P.func[fi] = (int32_t)s.funcs[fi].kind;
+                P.funcp |= (uint32_t)s.funcs[fi].kind << (4 * fi);
                 P.expo[fi] = (float)s.funcs[fi].expo;
+                for (int mt1 = 0; mt1 < s.mt1; ++mt1) P.nk2p[mt1] |= (uint32_t)s.nk2[mt1][fi] << (4 * fi);
             }
-            memcpy(P.nk2, s.nk2, sizeof P.nk2);
             if (si == 0) {
                 P.chunks = (const DChunk*)s.d_chunks.p;
                 P.runs = (const DRun*)s.d_runs.p;
@@ -965,7 +1003,8 @@ public:
                 // tile groups part, part + tile_parts, ...; aim at ~3 workgroups per CU in total
                 // cost(P) = rounds of resident workgroups x (weight copy + tile iterations per workgroup)
                 const int64_t g8 = (int64_t)(n_groups + 7) / 8 * 8;
-                const double capacity = 4096.0 / nw;   // resident workgroups: 256 CUs x 16 waves
+                size_t lds_probe = (size_t)npg * s.node_blocks * 1024 + (size_t)npg * s.bias_floats * 4 + (size_t)npg * s.kb1 * 8;
+                const double capacity = 256.0 * resident_blocks(pick_stage(s.mt1, s.mt2, T), nw * 64, lds_probe);
                 int tile_parts = 1;
                 double best = 1e300;
                 for (int pp = 1; pp <= tile_groups; ++pp) {
@@ -1017,6 +1056,18 @@ public:
     }
 
 private:
+    // resident workgroups per CU for (kernel, block size, LDS) — cached occupancy query
+    int resident_blocks(StageFn fn, int threads, size_t lds) {
+        set_lds_limit(fn, lds);
+        auto key = std::make_tuple((const void*)fn, threads, lds);
+        auto it = occ_.find(key);
+        if (it != occ_.end()) return it->second;
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)fn, threads, lds) != hipSuccess || nb < 1) nb = 1;
+        occ_[key] = nb;
+        return nb;
+    }
+
     void set_lds_limit(StageFn fn, size_t bytes) {
         if (bytes <= 64 * 1024) return;
         if (bytes > 160 * 1024) fail(HG_ERR_FORMAT, "fused: a node needs %zu bytes of LDS (> 160 KiB)", bytes);
@@ -1122,6 +1173,7 @@ private:
     std::vector<int32_t> col_base_;
     DevBuf d_col_base_, bufA_, bufB_;
     std::map<const void*, size_t> lds_set_;
+    std::map<std::tuple<const void*, int, size_t>, int> occ_;
     int max_nb_ = 0;
     int64_t padded_flops_ = 0, cap_rows_ = 0;
 };
@@ -1138,7 +1190,7 @@ std::unique_ptr<Executor> make_fused_executor(const TNode& root, std::string* wh
     for (auto& st : stages) {
         const FNode& f0 = st.nodes[0];
         if (f0.funcs.size() > (size_t)kMaxFuncs) {
-            if (why_not) *why_not = "more than 8 expansion functions";
+            if (why_not) *why_not = "more than 4 expansion functions";
             return nullptr;
         }
         for (auto& n : st.nodes) {

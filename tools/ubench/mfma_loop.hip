@@ -1,0 +1,86 @@
+// Microbenchmark: what does the inner loop shape of k_stage cost on gfx950?
+// build: hipcc -O3 --offload-arch=gfx950 mfma_loop.hip -o mfma_loop ; run: ./mfma_loop
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// MT = 4 m-tiles, T = 2 batch tiles -> 8 accumulators, 32 MFMAs per "K-block" iteration
+template <int V>
+__global__ void __launch_bounds__(512) k(const f32x4* __restrict__ w, const int2* __restrict__ tab, float* out, int iters, int nk_in) {
+    extern __shared__ f32x4 smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < 4096; i += blockDim.x) smem[i] = w[i];     // 64 KiB of "weights"
+    int2* st = (int2*)(smem + 4096);
+    if (tid < 64) st[tid] = tab[tid];
+    __syncthreads();
+    f32x4 acc[4][2];
+    for (int m = 0; m < 4; ++m) for (int t = 0; t < 2; ++t) acc[m][t] = f32x4{0, 0, 0, 0};
+    f32x4 bf[2] = {w[lane], w[64 + lane]};
+    f32x4 a[4], an[4];
+    const f32x4* wl = smem + lane;
+    if (V == 2) for (int m = 0; m < 4; ++m) a[m] = wl[m * 64];
+    int nk = nk_in;
+    for (int it = 0; it < iters; ++it) {
+        const int kb = it & 15;
+        if (V == 0) {
+            for (int m = 0; m < 4; ++m) a[m] = bf[m & 1];
+        } else if (V == 1 || V == 3 || V == 4) {
+            if (V == 4) {
+                int2 e = st[kb];
+                nk = __builtin_amdgcn_readfirstlane(e.y);
+            }
+            for (int m = 0; m < 4; ++m) a[m] = wl[(kb * 4 + m) * 64];
+        } else if (V == 2) {
+            const int kn = (it + 1) & 15;
+            for (int m = 0; m < 4; ++m) an[m] = wl[(kn * 4 + m) * 64];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if ((V == 3 || V == 4) && r >= nk) continue;
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[m][t] = MFMA16(a[m][r], bf[t][r], acc[m][t]);
+        }
+        if (V == 2) for (int m = 0; m < 4; ++m) a[m] = an[m];
+    }
+    f32x4 s = f32x4{0, 0, 0, 0};
+    for (int m = 0; m < 4; ++m) for (int t = 0; t < 2; ++t) s += acc[m][t];
+    out[(size_t)blockIdx.x * blockDim.x + tid] = s[0] + s[1] + s[2] + s[3];
+}
+
+template <int V>
+void run(const char* name, const f32x4* w, const int2* tab, float* out, int threads, int blocks_per_cu) {
+    const int iters = 4096;
+    const int blocks = 256 * blocks_per_cu;
+    size_t lds = 4096 * 16 + 64 * 8;
+    hipFuncSetAttribute((const void*)k<V>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k<V>, blocks, threads, lds, 0, w, tab, out, iters, 4);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k<V>, blocks, threads, lds, 0, w, tab, out, iters, 4);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    double flops = (double)blocks * (threads / 64) * iters * 32.0 * 2048.0;
+    printf("%-34s %4d thr x %d/CU: %7.3f ms  %6.1f TFLOP/s (%.0f%% of 157.3)\n", name, threads, blocks_per_cu, ms, flops / ms / 1e9, flops / ms / 1e9 / 157.3 * 100);
+}
+
+int main() {
+    f32x4* w; int2* tab; float* out;
+    hipMalloc(&w, 4096 * 16 + 4096); hipMalloc(&tab, 64 * 8); hipMalloc(&out, 256 * 4 * 1024 * 4);
+    std::vector<float> hw(4096 * 4 + 1024, 0.001f); hipMemcpy(w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice);
+    std::vector<int2> ht(64, int2{3, 4}); hipMemcpy(tab, ht.data(), 64 * 8, hipMemcpyHostToDevice);
+    for (int cfg = 0; cfg < 3; ++cfg) {
+        int thr = cfg == 0 ? 256 : 512, per = cfg == 2 ? 2 : 1;   // 1, 2, 4 waves per SIMD
+        run<0>("V0 registers only", w, tab, out, thr, per);
+        run<1>("V1 + A frags from LDS (just in time)", w, tab, out, thr, per);
+        run<2>("V2 + A frags from LDS (prefetched)", w, tab, out, thr, per);
+        run<3>("V3 V1 + nk branches", w, tab, out, thr, per);
+        run<4>("V4 V3 + LDS table/readfirstlane", w, tab, out, thr, per);
+    }
+    return 0;
+}
