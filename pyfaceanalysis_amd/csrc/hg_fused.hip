@@ -599,6 +599,135 @@ __global__ void __launch_bounds__(512) k_stage0(StageParams P) {
     }
 }
 
+// Stage 0, persistent + software-pipelined variant for small first-layer nodes (one K-block, one
+// tile in and out, <= 2 expansion functions, 16-byte contiguous receptive-field rows): the
+// workgroup owns one node chunk, keeps the weights of its nodes in REGISTERS (2 node slots per
+// wave), and sweeps tile groups part, part + tile_parts, ...  While tile group i is multiplied out
+// of the LDS tile, the row segments of tile group i+1 are already in flight from HBM into registers
+// (8 x 16 B per thread); they are written to LDS after the barrier that ends the compute phase.
+// No load is issued inside the compute phase, so the in-order vmcnt queue never forces the
+// prefetch to land early.
+template <int T, typename XT>
+__global__ void __launch_bounds__(512) k_stage0p(StageParams P) {
+    extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
+    float* lds = (float*)smem;
+    constexpr int NB = 8, NPW = 2;
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, nw = nthr >> 6, g = lane >> 4, j = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ci = blockIdx.x % P.n_chunks, part = blockIdx.x / P.n_chunks;
+    const DChunk ck = P.chunks[ci];
+    const XT* x = (const XT*)P.x;
+    const int stride = P.lds_stride;
+    const int n_groups = (P.n_tiles + T - 1) / T;
+    // --- per-thread staging bookkeeping (the same pieces for every tile group)
+    const int pps = ck.n_pieces, total = T * 16 * pps;
+    int p_col[NB], p_dst[NB];   // source column; (sub-image << 24 | LDS word offset) or -1
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const int idx = k * nthr + tid;
+        p_col[k] = 0;
+        p_dst[k] = -1;
+        if (idx < total) {
+            const int sj = idx / pps, pc = idx - sj * pps;
+            const int2 pcol = P.piece_col[ck.piece_begin + pc];
+            p_col[k] = pcol.x;
+            p_dst[k] = (sj << 24) | (sj * stride + pcol.y);
+        }
+    }
+    // --- weights of this wave's node slots, resident in registers for the whole sweep
+    int w_off[NPW];
+    f32x4 w_mu[NPW], w_a1[NPW], w_a2[NPW][2], w_b1[NPW], w_b2[NPW];
+    bool w_ok[NPW];
+#pragma unroll
+    for (int sl = 0; sl < NPW; ++sl) {
+        const int nl = wave + sl * nw;
+        w_ok[sl] = nl < ck.node_count;
+        const int ni = ck.node_begin + (w_ok[sl] ? nl : 0);
+        const size_t ent = (size_t)ni * 16 + g * 4;       // kb1 == 1
+        w_off[sl] = P.koff[ent];
+        w_mu[sl] = *(const f32x4*)(P.kmean + ent);
+        const f32x4* wp = P.afrag + (size_t)ni * P.node_blocks * 64 + lane;
+        w_a1[sl] = wp[0];
+        w_a2[sl][0] = wp[64];
+        w_a2[sl][1] = P.nf > 1 ? wp[128] : wp[64];
+        const float* bp = P.bias + (size_t)ni * P.bias_floats + g * 4;
+        w_b1[sl] = *(const f32x4*)bp;
+        w_b2[sl] = *(const f32x4*)(bp + 16);
+    }
+    const int nk1 = P.nk_last;
+    const int nk2a = P.nk2p[0] & 15, nk2b = (P.nk2p[0] >> 4) & 15;
+    const int fk0 = P.funcp & 15, fk1 = (P.funcp >> 4) & 15;
+    const float ex0 = P.expo[0], ex1 = P.expo[1];
+
+    auto fetch = [&](int grp, f32x4 (&v)[NB]) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int64_t row = (int64_t)grp * (T * 16) + (p_dst[k] >> 24);
+            if (p_dst[k] >= 0 && row < P.n_rows)
+                v[k] = Vec4Load<XT>::ld(x + row * P.ldx + p_col[k]);
+            else
+                v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    f32x4 v[NB];
+    if (part < n_groups) fetch(part, v);
+    for (int grp = part; grp < n_groups; grp += P.tile_parts) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k)
+            if (p_dst[k] >= 0) *(f32x4*)(lds + (p_dst[k] & 0xffffff)) = v[k];
+        if (tid < T * 16) lds[tid * stride + stride - 1] = 0.f;
+        __syncthreads();
+        if (grp + P.tile_parts < n_groups) fetch(grp + P.tile_parts, v);
+        int tile[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) tile[t] = grp * T + t;
+#pragma unroll
+        for (int sl = 0; sl < NPW; ++sl) {
+            if (!w_ok[sl]) continue;
+            const int ni = ck.node_begin + wave + sl * nw;
+            f32x4 z[1][T], y[1][T], bf[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                bf[t] = *(const f32x4*)(lds + (t * 16 + j) * stride + w_off[sl]) - w_mu[sl];
+                z[0][t] = w_b1[sl];
+                y[0][t] = w_b2[sl];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (r < nk1) {
+#pragma unroll
+                    for (int t = 0; t < T; ++t) z[0][t] = MFMA16(w_a1[sl][r], bf[t][r], z[0][t]);
+                }
+            {
+                f32x4 e[T];
+#pragma unroll
+                for (int t = 0; t < T; ++t) e[t] = apply_func(fk0, ex0, z[0][t]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (r < nk2a) {
+#pragma unroll
+                        for (int t = 0; t < T; ++t) y[0][t] = MFMA16(w_a2[sl][0][r], e[t][r], y[0][t]);
+                    }
+            }
+            if (P.nf > 1) {
+                f32x4 e[T];
+#pragma unroll
+                for (int t = 0; t < T; ++t) e[t] = apply_func(fk1, ex1, z[0][t]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (r < nk2b) {
+#pragma unroll
+                        for (int t = 0; t < T; ++t) y[0][t] = MFMA16(w_a2[sl][1][r], e[t][r], y[0][t]);
+                    }
+            }
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+                if (tile[t] < P.n_tiles) P.out[((size_t)tile[t] * P.nb_out + ni) * 64 + lane] = y[0][t];
+        }
+        __syncthreads();
+    }
+}
+
 // Fragment order -> caller's row-major y (first y_cols columns).
 template <typename YT>
 __global__ void k_unpack(const float* __restrict__ act, int nb, const int32_t* __restrict__ col_base, YT* __restrict__ y,
@@ -689,7 +818,7 @@ struct HostStage {
     std::vector<DRun> runs;
     std::vector<int32_t> piece_col, koff;
     std::vector<float> kmean;
-    int lds_stride = 0;
+    int lds_stride = 0, max_chunk_nodes = 0, max_chunk_pieces = 0;
     int64_t mfma_per_tile = 0;
     std::string name;
     DevBuf d_afrag, d_bias, d_kb1tab, d_chunks, d_runs, d_piece, d_koff, d_kmean;
@@ -737,13 +866,18 @@ public:
                 if (si == 0) {
                     const int nkb = (nd.in_dim + 15) / 16;
                     for (int kb = 0; kb < nkb; ++kb) {
-                        int valid = std::min(16, nd.in_dim - kb * 16);
+                        // K slot (k-step r, lane group g) <- input position s0_pos(r, g) of this block
+                        int valid = std::min(16, nd.in_dim - kb * 16), nk = 0;
                         K.src.push_back(0);
-                        K.nk.push_back((valid + 3) / 4);
                         for (int q = 0; q < 16; ++q) {
                             K.kpos.emplace_back();
-                            if (q < valid) K.kpos.back().push_back(kb * 16 + q);
+                            const int pos = s0_pos(q >> 2, q & 3);
+                            if (pos < valid) {
+                                K.kpos.back().push_back(kb * 16 + pos);
+                                nk = std::max(nk, (q >> 2) + 1);
+                            }
                         }
+                        K.nk.push_back(nk);
                     }
                 } else {
                     std::map<int, int> blk_index;
@@ -974,12 +1108,23 @@ public:
                 P.vec4 = (s.vec_ok && ldx % 4 == 0 && ((uintptr_t)x % valign) == 0 && (ldx * esz) % valign == 0) ? 1 : 0;
                 const int T = (n_tiles >= 4 && s.mt1 * s.mt2 <= 4) ? 4 : 1;
                 const int groups = (n_tiles + T - 1) / T;
-                const int64_t blocks = (int64_t)groups * P.n_chunks;
-                if (blocks > 0x7fffffffll) fail(HG_ERR_ARG, "batch too large");
                 size_t lds_bytes = (size_t)T * 16 * s.lds_stride * 4;
-                StageFn fn = pick_stage0(s.mt1, s.mt2, T, x_dtype);
-                set_lds_limit(fn, lds_bytes);
-                hipLaunchKernelGGL(fn, (unsigned)blocks, T == 4 ? 512 : 256, lds_bytes, st, P);
+                const bool persistent = T == 4 && P.vec4 && s.contig4 && s.has_exp && s.mt1 == 1 && s.mt2 == 1 && s.kb1 == 1 &&
+                                        s.nf <= 2 && s.max_chunk_nodes <= 16 && 64 * s.max_chunk_pieces <= 8 * 512;
+                if (persistent) {
+                    StageFn fn = x_dtype == HG_U8 ? (StageFn)k_stage0p<4, uint8_t>
+                                 : x_dtype == HG_F32 ? (StageFn)k_stage0p<4, float> : (StageFn)k_stage0p<4, double>;
+                    const int occ = resident_blocks(fn, 512, lds_bytes);
+                    int parts = std::max(1, std::min(groups, 256 * occ / std::max(1, P.n_chunks)));
+                    P.tile_parts = parts;
+                    hipLaunchKernelGGL(fn, (unsigned)(P.n_chunks * parts), 512, lds_bytes, st, P);
+                } else {
+                    const int64_t blocks = (int64_t)groups * P.n_chunks;
+                    if (blocks > 0x7fffffffll) fail(HG_ERR_ARG, "batch too large");
+                    StageFn fn = pick_stage0(s.mt1, s.mt2, T, x_dtype);
+                    set_lds_limit(fn, lds_bytes);
+                    hipLaunchKernelGGL(fn, (unsigned)blocks, T == 4 ? 512 : 256, lds_bytes, st, P);
+                }
             } else {
                 // node groups sized so a group's weights are ~64 KiB of LDS (always >= 1 node)
                 const int npg = std::max(1, std::min(s.n_nodes, kWeightLdsKiB / std::max(1, s.node_blocks)));
@@ -1087,6 +1232,16 @@ private:
             kb1 = std::max(kb1, (nd.in_dim + 15) / 16);
             max_in = std::max(max_in, nd.in_dim);
         }
+        // K-slot assignment inside a block of 16 input positions: slot (r, g) <- position 4r+g, or the
+        // transposed 4g+r when that makes the four k-steps of a lane contiguous in the input row
+        // (e.g. 4-pixel-wide receptive fields: one ds_read_b128 per fragment instead of four b32)
+        s0_transpose_ = true;
+        for (auto& nd : st.nodes) {
+            for (int c = 0; c < nd.in_dim && s0_transpose_; c += 4)
+                for (int r = 1; r < 4 && c + r < nd.in_dim; ++r)
+                    if (st.conn[nd.in_off + c + r] != st.conn[nd.in_off + c] + r) s0_transpose_ = false;
+            if (nd.in_dim % 4) s0_transpose_ = false;
+        }
         const int col_budget = std::max(kStage0ChunkCols, (max_in + 3) / 4 * 4);
         if (col_budget > 2048) fail(HG_ERR_FORMAT, "fused: first-layer node with %d inputs", max_in);
         hs.koff.assign((size_t)n * kb1 * 16, -1);
@@ -1136,7 +1291,7 @@ private:
                 for (int kb = 0; kb < kb1; ++kb)
                     for (int g = 0; g < 4; ++g)
                         for (int r = 0; r < 4; ++r) {
-                            int c = kb * 16 + 4 * r + g;
+                            int c = kb * 16 + s0_pos(r, g);
                             size_t e = (((size_t)k * kb1 + kb) * 4 + g) * 4 + r;
                             if (c < nd.in_dim) {
                                 hs.koff[e] = lds_of[st.conn[nd.in_off + c]];
@@ -1145,6 +1300,8 @@ private:
                         }
             }
             hs.chunks.push_back(ck);
+            hs.max_chunk_nodes = std::max(hs.max_chunk_nodes, ck.node_count);
+            hs.max_chunk_pieces = std::max(hs.max_chunk_pieces, ck.n_pieces);
             ni = n1;
         }
         // Row stride of the LDS tile: >= max_cols + 1 (last word = the zero column padded k positions
@@ -1168,7 +1325,10 @@ private:
         hs.vec_ok = vec_ok;
     }
 
+    int s0_pos(int r, int g) const { return s0_transpose_ ? 4 * g + r : 4 * r + g; }
+
     int in_dim_, out_dim_;
+    bool s0_transpose_ = false;
     std::vector<HostStage> stages_;
     std::vector<int32_t> col_base_;
     DevBuf d_col_base_, bufA_, bufB_;
