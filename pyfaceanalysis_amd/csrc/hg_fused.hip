@@ -478,6 +478,109 @@ __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
     }
 }
 
+// Stages > 0 with FEW nodes (the top of the hierarchy: 16, 8, 4, 2, 1 nodes).  There are not enough
+// (node, tile) pairs to fill 1024 SIMDs with whole nodes, and copying 64 KiB of weights into LDS
+// per workgroup is all latency.  Here a workgroup of max(MT1, MT2) waves shares ONE node and T
+// tiles; wave w computes m-tile w of GEMM 1 and later m-tile w of GEMM 2, so every weight block is
+// read by exactly one wave (straight from L2, all loads of a phase issued up front), and the
+// expanded z tiles are exchanged through 2*MT1*T KiB of LDS.
+template <int T>
+__global__ void __launch_bounds__(256) k_stage_splitm(StageParams P, int mt1n, int mt2n) {
+    extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
+    constexpr int KB = 8;   // K-blocks loaded per batch
+    const int lane = threadIdx.x & 63, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int node = blockIdx.x % P.n_nodes, grp = blockIdx.x / P.n_nodes;
+    int tile[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) tile[t] = grp * T + t;
+    uint32_t trow[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) trow[t] = (uint32_t)(tile[t] < P.n_tiles ? tile[t] : tile[0]) * (uint32_t)P.nb_in;
+    const f32x4* wnode = P.afrag + (size_t)node * P.node_blocks * 64 + lane;
+    const float* bnode = P.bias + (size_t)node * P.bias_floats + g * 4;
+    const int2* kt = P.kb1tab + (size_t)node * P.kb1;
+    const int nf = P.nf;
+    // GEMM-2 weights of this wave's output tile do not depend on z: fetch them first
+    f32x4 a2[KB];
+    const int k2n = mt1n * nf;
+    if (P.has_exp && w < mt2n) {
+#pragma unroll
+        for (int k = 0; k < KB; ++k)
+            if (k < k2n) a2[k] = wnode[((size_t)P.kb1 * mt1n + (size_t)k * mt2n + w) * 64];
+    }
+    f32x4 z[T];
+    if (w < mt1n) {
+        const f32x4 bb = *(const f32x4*)(bnode + w * 16);
+#pragma unroll
+        for (int t = 0; t < T; ++t) z[t] = bb;
+        for (int k0 = 0; k0 < P.kb1; k0 += KB) {
+            f32x4 a1[KB], bf[KB][T];
+            int nks[KB];
+#pragma unroll
+            for (int k = 0; k < KB; ++k) {
+                nks[k] = 0;
+                if (k0 + k < P.kb1) {
+                    const int2 e = kt[k0 + k];
+                    nks[k] = e.y;
+                    a1[k] = wnode[((size_t)(k0 + k) * mt1n + w) * 64];
+#pragma unroll
+                    for (int t = 0; t < T; ++t) bf[k][t] = P.in[(size_t)(trow[t] + e.x) * 64 + lane];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < KB; ++k) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (r < nks[k]) {
+#pragma unroll
+                        for (int t = 0; t < T; ++t) z[t] = MFMA16(a1[k][r], bf[k][t][r], z[t]);
+                    }
+            }
+        }
+        if (!P.has_exp) {
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+                if (tile[t] < P.n_tiles) P.out[((size_t)tile[t] * P.nb_out + node * P.mto + w) * 64 + lane] = z[t];
+            return;   // linear stage: no barrier follows on any path
+        }
+        for (int fi = 0; fi < nf; ++fi) {
+            const int fk = (P.funcp >> (4 * fi)) & 15;
+            const float ex = P.expo[fi];
+#pragma unroll
+            for (int t = 0; t < T; ++t) smem[((fi * mt1n + w) * T + t) * 64 + lane] = apply_func(fk, ex, z[t]);
+        }
+    } else if (!P.has_exp) {
+        return;
+    }
+    __syncthreads();
+    if (w >= mt2n) return;
+    f32x4 y[T];
+    {
+        const f32x4 bb = *(const f32x4*)(bnode + (mt1n + w) * 16);
+#pragma unroll
+        for (int t = 0; t < T; ++t) y[t] = bb;
+    }
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+        if (k >= k2n) continue;
+        const int mt1 = k / nf, fi = k - mt1 * nf;
+        const int nk = (P.nk2p[mt1] >> (4 * fi)) & 15;
+        f32x4 e[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) e[t] = smem[((fi * mt1n + mt1) * T + t) * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (r < nk) {
+#pragma unroll
+                for (int t = 0; t < T; ++t) y[t] = MFMA16(a2[k][r], e[t][r], y[t]);
+            }
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+        if (tile[t] < P.n_tiles) P.out[((size_t)tile[t] * P.nb_out + node * P.mto + w) * 64 + lane] = y[t];
+}
+
 // Stage 0: input = caller's row-major sub-image matrix.  The WG stages, for T batch tiles, the
 // column runs its node chunk needs (full 16 B/lane coalesced row segments when alignment allows)
 // into an LDS tile [sub-image][column]; each wave then takes every 4th node of the chunk and
@@ -1126,6 +1229,20 @@ public:
                     hipLaunchKernelGGL(fn, (unsigned)blocks, T == 4 ? 512 : 256, lds_bytes, st, P);
                 }
             } else {
+                if (s.n_nodes <= 4 && s.mt1 * s.nf <= 8 && (int64_t)s.n_nodes * n_tiles <= 8192) {
+                    // top of the hierarchy: split the m-tiles of a node over the waves of a small workgroup
+                    const int T = n_tiles >= 2 * 256 / std::max(1, s.n_nodes) ? 2 : 1;
+                    const int groups = (n_tiles + T - 1) / T;
+                    const int nwv = std::max(s.mt1, s.has_exp ? s.mt2 : 1);
+                    size_t lds_bytes = (size_t)std::max(1, s.nf) * s.mt1 * T * 1024;
+                    if (T == 2)
+                        hipLaunchKernelGGL(k_stage_splitm<2>, (unsigned)(groups * s.n_nodes), nwv * 64, lds_bytes, st, P, s.mt1, s.mt2);
+                    else
+                        hipLaunchKernelGGL(k_stage_splitm<1>, (unsigned)(groups * s.n_nodes), nwv * 64, lds_bytes, st, P, s.mt1, s.mt2);
+                    std::swap(cur, nxt);
+                    if (ev) HG_HIP(hipEventRecord(ev[e++], st));
+                    continue;
+                }
                 // node groups sized so a group's weights are ~64 KiB of LDS (always >= 1 node)
                 const int npg = std::max(1, std::min(s.n_nodes, kWeightLdsKiB / std::max(1, s.node_blocks)));
                 const int n_groups = (s.n_nodes + npg - 1) / npg;
