@@ -163,23 +163,32 @@ def main():
         value = total_rows * args.steps / elapsed
         flops_row = int(info.flops_per_row)
         # dominant kernel = the stage with the largest average duration
-        layer_flops = synth.flops_per_row  # noqa: F841  (algorithmic figure per layer below)
-        per_layer = []
-        li = 0
+        per_layer = []           # (algorithmic FLOPs, algorithmic bytes) per sub-image for every layer kernel
+        in_bytes = SIDE * SIDE * in_dt.itemsize
         for nd in nodes:
             if type(nd).__name__ in ("Layer", "CloneLayer"):
-                per_layer.append(synth.flops_per_row([nd]))
-                li += 1
+                out_bytes = nd.output_dim * 4
+                per_layer.append((synth.flops_per_row([nd]), in_bytes + out_bytes))
+                in_bytes = out_bytes
         roof = None
         if stage_rows:
             k_idx = max(range(len(stage_rows)), key=lambda i: stage_rows[i][1])
             k_name, k_ms = stage_rows[k_idx]
             if info.plan_kind == 1 and k_idx < len(per_layer):
-                k_flops = per_layer[k_idx] * rows            # algorithmic FLOPs of that layer per launch
-                ach = k_flops / (k_ms * 1e-3) / 1e12
-                roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
-                        "frac": ach / PEAK_MFMA_F32_TFLOPS, "traffic": None, "kernel": k_name,
-                        "kernel_ms": k_ms, "flops_per_launch": k_flops}
+                # the roofline that binds this kernel: arithmetic intensity against the ridge point
+                k_flops, k_bytes = per_layer[k_idx][0] * rows, per_layer[k_idx][1] * rows
+                ridge = PEAK_MFMA_F32_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+                if k_flops / k_bytes >= ridge:
+                    ach = k_flops / (k_ms * 1e-3) / 1e12
+                    roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
+                            "frac": ach / PEAK_MFMA_F32_TFLOPS, "traffic": None}
+                else:
+                    ach = k_bytes / (k_ms * 1e-3) / 1e9
+                    roof = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                            "frac": ach / PEAK_HBM_GBS, "traffic": None}
+                roof.update({"kernel": k_name, "kernel_ms": k_ms, "flops_per_launch": k_flops,
+                             "algorithmic_bytes_per_launch": k_bytes,
+                             "arithmetic_intensity": k_flops / k_bytes, "ridge": ridge})
             else:
                 gb = rows * SIDE * SIDE * in_dt.itemsize / 1e9
                 ach = gb / (k_ms * 1e-3)

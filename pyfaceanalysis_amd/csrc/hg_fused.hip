@@ -831,6 +831,196 @@ __global__ void __launch_bounds__(512) k_stage0p(StageParams P) {
     }
 }
 
+// Stages 0 AND 1 in one persistent kernel (the U11L front end): same structure as k_stage0p, but a
+// wave's two node slots are ADJACENT layer-0 nodes 2w, 2w+1 — the two children of layer-1 node w of
+// the chunk — so their output accumulators are, in registers, the two K-blocks of that layer-1
+// node's first affine.  Layer-1 weights (4 + 8 fragment blocks) are register resident too.  The
+// layer-0 activation (64 KiB per sub-image written and read back) never exists in memory.
+// Requirements checked on the host: layer 0 as for k_stage0p; layer-1 node n reads exactly the
+// blocks of layer-0 nodes 2n and 2n+1; both layer-1 affines have <= 32 outputs; same <= 2 functions.
+template <typename XT>
+__global__ void __launch_bounds__(512) k_stage01p(StageParams P, StageParams Q) {
+    extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
+    float* lds = (float*)smem;
+    constexpr int T = 2, NB = 4, NPW = 2;
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, g = lane >> 4, j = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ci = blockIdx.x % P.n_chunks, part = blockIdx.x / P.n_chunks;
+    const DChunk ck = P.chunks[ci];
+    const XT* x = (const XT*)P.x;
+    const int stride = P.lds_stride;
+    const int n_groups = (P.n_tiles + T - 1) / T;
+    const int pps = ck.n_pieces, total = T * 16 * pps;
+    int p_col[NB], p_dst[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const int idx = k * nthr + tid;
+        p_col[k] = 0;
+        p_dst[k] = -1;
+        if (idx < total) {
+            const int sj = idx / pps, pc = idx - sj * pps;
+            const int2 pcol = P.piece_col[ck.piece_begin + pc];
+            p_col[k] = pcol.x;
+            p_dst[k] = (sj << 24) | (sj * stride + pcol.y);
+        }
+    }
+    // layer-0 weights of the two slots
+    int w_off[NPW];
+    f32x4 w_mu[NPW], w_a1[NPW], w_a2[NPW][2], w_b1[NPW], w_b2[NPW];
+    const bool w_ok = 2 * wave + 1 < ck.node_count;    // both children present (chunks hold whole pairs)
+#pragma unroll
+    for (int sl = 0; sl < NPW; ++sl) {
+        const int ni = ck.node_begin + (w_ok ? 2 * wave + sl : 0);
+        const size_t ent = (size_t)ni * 16 + g * 4;
+        w_off[sl] = P.koff[ent];
+        w_mu[sl] = *(const f32x4*)(P.kmean + ent);
+        const f32x4* wp = P.afrag + (size_t)ni * P.node_blocks * 64 + lane;
+        w_a1[sl] = wp[0];
+        w_a2[sl][0] = wp[64];
+        w_a2[sl][1] = P.nf > 1 ? wp[128] : wp[64];
+        const float* bp = P.bias + (size_t)ni * P.bias_floats + g * 4;
+        w_b1[sl] = *(const f32x4*)bp;
+        w_b2[sl] = *(const f32x4*)(bp + 16);
+    }
+    // layer-1 node of this wave: A1 [kb 0..1][mt 0..1], A2 [mt1 0..1][fi 0..1][mt2 0..1], biases
+    const int n1 = (ck.node_begin >> 1) + (w_ok ? wave : 0);
+    f32x4 q_a1[2][2], q_a2[2][2][2], q_b1[2], q_b2[2];
+    {
+        const f32x4* wq = Q.afrag + (size_t)n1 * Q.node_blocks * 64 + lane;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) q_a1[kb][mt] = wq[(kb * 2 + mt) * 64];
+        const f32x4* wq2 = wq + Q.kb1 * 2 * 64;
+#pragma unroll
+        for (int m1 = 0; m1 < 2; ++m1)
+#pragma unroll
+            for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) q_a2[m1][fi][mt] = wq2[((m1 * Q.nf + (fi < Q.nf ? fi : 0)) * 2 + mt) * 64];
+        const float* bq = Q.bias + (size_t)n1 * Q.bias_floats + g * 4;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            q_b1[mt] = *(const f32x4*)(bq + mt * 16);
+            q_b2[mt] = *(const f32x4*)(bq + 32 + mt * 16);
+        }
+    }
+    const int nk1 = P.nk_last;
+    const int nk2a = P.nk2p[0] & 15, nk2b = (P.nk2p[0] >> 4) & 15;
+    const int fk0 = P.funcp & 15, fk1 = (P.funcp >> 4) & 15;
+    const float ex0 = P.expo[0], ex1 = P.expo[1];
+    const int qfk0 = Q.funcp & 15, qfk1 = (Q.funcp >> 4) & 15;
+    const float qex0 = Q.expo[0], qex1 = Q.expo[1];
+
+    auto fetch = [&](int grp, f32x4 (&v)[NB]) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int64_t row = (int64_t)grp * (T * 16) + (p_dst[k] >> 24);
+            if (p_dst[k] >= 0 && row < P.n_rows)
+                v[k] = Vec4Load<XT>::ld(x + row * P.ldx + p_col[k]);
+            else
+                v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    f32x4 v[NB];
+    if (part < n_groups) fetch(part, v);
+    for (int grp = part; grp < n_groups; grp += P.tile_parts) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k)
+            if (p_dst[k] >= 0) *(f32x4*)(lds + (p_dst[k] & 0xffffff)) = v[k];
+        if (tid < T * 16) lds[tid * stride + stride - 1] = 0.f;
+        __syncthreads();
+        if (grp + P.tile_parts < n_groups) fetch(grp + P.tile_parts, v);
+        if (w_ok) {
+            int tile[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) tile[t] = grp * T + t;
+            // ---- layer 0: two children
+            f32x4 y0[NPW][T];
+#pragma unroll
+            for (int sl = 0; sl < NPW; ++sl) {
+                f32x4 z[T], bf[T];
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    bf[t] = *(const f32x4*)(lds + (t * 16 + j) * stride + w_off[sl]) - w_mu[sl];
+                    z[t] = w_b1[sl];
+                    y0[sl][t] = w_b2[sl];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (r < nk1) {
+#pragma unroll
+                        for (int t = 0; t < T; ++t) z[t] = MFMA16(w_a1[sl][r], bf[t][r], z[t]);
+                    }
+                {
+                    f32x4 e[T];
+#pragma unroll
+                    for (int t = 0; t < T; ++t) e[t] = apply_func(fk0, ex0, z[t]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (r < nk2a) {
+#pragma unroll
+                            for (int t = 0; t < T; ++t) y0[sl][t] = MFMA16(w_a2[sl][0][r], e[t][r], y0[sl][t]);
+                        }
+                }
+                if (P.nf > 1) {
+                    f32x4 e[T];
+#pragma unroll
+                    for (int t = 0; t < T; ++t) e[t] = apply_func(fk1, ex1, z[t]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (r < nk2b) {
+#pragma unroll
+                            for (int t = 0; t < T; ++t) y0[sl][t] = MFMA16(w_a2[sl][1][r], e[t][r], y0[sl][t]);
+                        }
+                }
+            }
+            // ---- layer 1: K-blocks of the first affine are the children's accumulators
+            f32x4 z1[2][T], y1[2][T];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    z1[mt][t] = q_b1[mt];
+                    y1[mt][t] = q_b2[mt];
+                }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int t = 0; t < T; ++t) z1[mt][t] = MFMA16(q_a1[kb][mt][r], y0[kb][t][r], z1[mt][t]);
+#pragma unroll
+            for (int m1 = 0; m1 < 2; ++m1) {
+#pragma unroll
+                for (int fi = 0; fi < 2; ++fi) {
+                    const int nk = fi < Q.nf ? (int)((Q.nk2p[m1] >> (4 * fi)) & 15) : 0;
+                    if (nk == 0) continue;
+                    f32x4 e[T];
+#pragma unroll
+                    for (int t = 0; t < T; ++t) e[t] = apply_func(fi == 0 ? qfk0 : qfk1, fi == 0 ? qex0 : qex1, z1[m1][t]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (r < nk) {
+#pragma unroll
+                            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                                for (int t = 0; t < T; ++t) y1[mt][t] = MFMA16(q_a2[m1][fi][mt][r], e[t][r], y1[mt][t]);
+                        }
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+                    if (tile[t] < P.n_tiles) Q.out[((size_t)tile[t] * Q.nb_out + (size_t)n1 * Q.mto + mt) * 64 + lane] = y1[mt][t];
+        }
+        __syncthreads();
+    }
+}
+
 // Fragment order -> caller's row-major y (first y_cols columns).
 template <typename YT>
 __global__ void k_unpack(const float* __restrict__ act, int nb, const int32_t* __restrict__ col_base, YT* __restrict__ y,
@@ -847,6 +1037,7 @@ __global__ void k_unpack(const float* __restrict__ act, int nb, const int32_t* _
 
 // ---- launch tables -----------------------------------------------------------------------------
 typedef void (*StageFn)(StageParams);
+typedef void (*StageFn2)(StageParams, StageParams);
 
 template <int MT1, int MT2>
 StageFn pick_stage_t(int T) {
@@ -1111,6 +1302,10 @@ public:
                << " blocks/tile";
             hs.name = os.str();
         }
+        fuse01_ = can_fuse01();
+        if (fuse01_) {
+            stages_[0].name += "  [+ stage 1 fused in the same persistent kernel when the input allows 16-byte loads]";
+        }
         col_base_.resize(out_dim_);
         for (int c = 0; c < out_dim_; ++c) {
             int q = prev_q[c];
@@ -1172,27 +1367,31 @@ public:
         f32x4* nxt = (f32x4*)bufB_.p;
         for (size_t si = 0; si < stages_.size(); ++si) {
             HostStage& s = stages_[si];
-            StageParams P{};
-            P.afrag = (const f32x4*)s.d_afrag.p;
-            P.bias = (const float*)s.d_bias.p;
-            P.kb1tab = (const int2*)s.d_kb1tab.p;
-            P.in = cur;
-            P.out = nxt;
-            P.n_nodes = s.n_nodes;
-            P.kb1 = s.kb1;
-            P.nf = s.nf;
-            P.has_exp = s.has_exp ? 1 : 0;
-            P.node_blocks = s.node_blocks;
-            P.bias_floats = s.bias_floats;
-            P.n_tiles = n_tiles;
-            P.nb_in = s.nb_in;
-            P.nb_out = s.nb_out;
-            P.mto = s.mto;
-            for (int fi = 0; fi < s.nf; ++fi) {
-                P.funcp |= (uint32_t)s.funcs[fi].kind << (4 * fi);
-                P.expo[fi] = (float)s.funcs[fi].expo;
-                for (int mt1 = 0; mt1 < s.mt1; ++mt1) P.nk2p[mt1] |= (uint32_t)s.nk2[mt1][fi] << (4 * fi);
-            }
+            auto base_params = [&](HostStage& hs, const f32x4* in, f32x4* out) {
+                StageParams R{};
+                R.afrag = (const f32x4*)hs.d_afrag.p;
+                R.bias = (const float*)hs.d_bias.p;
+                R.kb1tab = (const int2*)hs.d_kb1tab.p;
+                R.in = in;
+                R.out = out;
+                R.n_nodes = hs.n_nodes;
+                R.kb1 = hs.kb1;
+                R.nf = hs.nf;
+                R.has_exp = hs.has_exp ? 1 : 0;
+                R.node_blocks = hs.node_blocks;
+                R.bias_floats = hs.bias_floats;
+                R.n_tiles = n_tiles;
+                R.nb_in = hs.nb_in;
+                R.nb_out = hs.nb_out;
+                R.mto = hs.mto;
+                for (int fi = 0; fi < hs.nf; ++fi) {
+                    R.funcp |= (uint32_t)hs.funcs[fi].kind << (4 * fi);
+                    R.expo[fi] = (float)hs.funcs[fi].expo;
+                    for (int mt1 = 0; mt1 < hs.mt1; ++mt1) R.nk2p[mt1] |= (uint32_t)hs.nk2[mt1][fi] << (4 * fi);
+                }
+                return R;
+            };
+            StageParams P = base_params(s, cur, nxt);
             if (si == 0) {
                 P.chunks = (const DChunk*)s.d_chunks.p;
                 P.runs = (const DRun*)s.d_runs.p;
@@ -1212,6 +1411,35 @@ public:
                 const int T = (n_tiles >= 4 && s.mt1 * s.mt2 <= 4) ? 4 : 1;
                 const int groups = (n_tiles + T - 1) / T;
                 size_t lds_bytes = (size_t)T * 16 * s.lds_stride * 4;
+                if (fuse01_ && P.vec4 && n_tiles >= 2) {
+                    // layers 0 and 1 in one persistent kernel; layer 1 writes where its own launch would
+                    StageParams Q = base_params(stages_[1], nullptr, cur);
+                    StageFn2 fn = x_dtype == HG_U8 ? (StageFn2)k_stage01p<uint8_t>
+                                  : x_dtype == HG_F32 ? (StageFn2)k_stage01p<float> : (StageFn2)k_stage01p<double>;
+                    const size_t lds2 = (size_t)2 * 16 * s.lds_stride * 4;
+                    const int groups2 = (n_tiles + 1) / 2;
+                    int occ = 1;
+                    {
+                        auto key = std::make_tuple((const void*)fn, 512, lds2);
+                        auto it = occ_.find(key);
+                        if (it == occ_.end()) {
+                            int nb = 0;
+                            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)fn, 512, lds2) != hipSuccess || nb < 1) nb = 1;
+                            occ_[key] = nb;
+                            occ = nb;
+                        } else {
+                            occ = it->second;
+                        }
+                    }
+                    P.tile_parts = std::max(1, std::min(groups2, 256 * occ / std::max(1, P.n_chunks)));
+                    hipLaunchKernelGGL(fn, (unsigned)(P.n_chunks * P.tile_parts), 512, lds2, st, P, Q);
+                    if (ev) {
+                        HG_HIP(hipEventRecord(ev[e++], st));   // stage 0 (carries the fused time)
+                        HG_HIP(hipEventRecord(ev[e++], st));   // stage 1 (fused: no launch of its own)
+                    }
+                    si = 1;   // cur / nxt unchanged: stage 2 reads `cur`
+                    continue;
+                }
                 const bool persistent = T == 4 && P.vec4 && s.contig4 && s.has_exp && s.mt1 == 1 && s.mt2 == 1 && s.kb1 == 1 &&
                                         s.nf <= 2 && s.max_chunk_nodes <= 16 && 64 * s.max_chunk_pieces <= 8 * 512;
                 if (persistent) {
@@ -1442,10 +1670,27 @@ private:
         hs.vec_ok = vec_ok;
     }
 
+    // Layers 0 and 1 can share one kernel when a wave's two layer-0 node slots are exactly the two
+    // children of one layer-1 node (see k_stage01p).
+    bool can_fuse01() const {
+        if (stages_.size() < 2) return false;
+        const HostStage& a = stages_[0];
+        const HostStage& b = stages_[1];
+        if (!(a.has_exp && a.mt1 == 1 && a.mt2 == 1 && a.kb1 == 1 && a.nf >= 1 && a.nf <= 2 && a.contig4 && a.vec_ok)) return false;
+        if (a.max_chunk_nodes > 16 || a.max_chunk_pieces > 64) return false;
+        for (auto& c : a.chunks)
+            if ((c.node_begin & 1) || (c.node_count & 1)) return false;
+        if (!(b.has_exp && b.mt1 == 2 && b.mt2 == 2 && b.kb1 == 2 && b.nf >= 1 && b.nf <= 2)) return false;
+        if (b.n_nodes * 2 != a.n_nodes) return false;
+        for (int n = 0; n < b.n_nodes; ++n)
+            if (b.kb1tab[(size_t)n * 4] != 2 * n || b.kb1tab[(size_t)n * 4 + 2] != 2 * n + 1) return false;
+        return true;
+    }
+
     int s0_pos(int r, int g) const { return s0_transpose_ ? 4 * g + r : 4 * r + g; }
 
     int in_dim_, out_dim_;
-    bool s0_transpose_ = false;
+    bool s0_transpose_ = false, fuse01_ = false;
     std::vector<HostStage> stages_;
     std::vector<int32_t> col_base_;
     DevBuf d_col_base_, bufA_, bufB_;
