@@ -164,31 +164,54 @@ def main():
         flops_row = int(info.flops_per_row)
         # dominant kernel = the stage with the largest average duration
         per_layer = []           # (algorithmic FLOPs, algorithmic bytes) per sub-image for every layer kernel
+        nodes_out_bytes = []     # fp32 bytes of each layer's output per sub-image
         in_bytes = SIDE * SIDE * in_dt.itemsize
         for nd in nodes:
             if type(nd).__name__ in ("Layer", "CloneLayer"):
                 out_bytes = nd.output_dim * 4
                 per_layer.append((synth.flops_per_row([nd]), in_bytes + out_bytes))
+                nodes_out_bytes.append(out_bytes)
                 in_bytes = out_bytes
         roof = None
         if stage_rows:
-            k_idx = max(range(len(stage_rows)), key=lambda i: stage_rows[i][1])
-            k_name, k_ms = stage_rows[k_idx]
-            if info.plan_kind == 1 and k_idx < len(per_layer):
+            # kernels actually launched: a stage that reports ~0 ms was fused into the previous kernel
+            # (layers 0+1 share one persistent kernel): merge its FLOPs, keep first input / last output bytes
+            kernels = []     # [name, ms, flops/row, bytes/row]
+            for i, (nm, ms) in enumerate(stage_rows):
+                fl, by = per_layer[i] if (info.plan_kind == 1 and i < len(per_layer)) else (0, 0)
+                if kernels and ms < 1e-3 and info.plan_kind == 1 and i < len(per_layer):
+                    kernels[-1][2] += fl
+                    kernels[-1][3] += nodes_out_bytes[i] - nodes_out_bytes[i - 1]     # swap the intermediate output for the final one
+                    kernels[-1][0] += " + " + nm.split(":")[0]
+                else:
+                    kernels.append([nm, ms, fl, by])
+            k_pos = max(range(len(kernels)), key=lambda i: kernels[i][1])
+            k_name, k_ms, k_fl, k_by = kernels[k_pos]
+            traffic = None
+            try:      # HBM bytes of this launch from the committed PMC profile of the same configuration
+                if rows == ROWS_PER_GPU and in_dt == np.float32 and world == 1:
+                    tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+                    for key, val in tj.items():
+                        if key.startswith("%d|" % k_pos):
+                            traffic = val["hbm_read_bytes"] + val["hbm_write_bytes"]
+            except Exception:
+                traffic = None
+            if info.plan_kind == 1 and k_fl > 0:
                 # the roofline that binds this kernel: arithmetic intensity against the ridge point
-                k_flops, k_bytes = per_layer[k_idx][0] * rows, per_layer[k_idx][1] * rows
+                k_flops, k_bytes = k_fl * rows, k_by * rows
                 ridge = PEAK_MFMA_F32_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
                 if k_flops / k_bytes >= ridge:
                     ach = k_flops / (k_ms * 1e-3) / 1e12
                     roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
-                            "frac": ach / PEAK_MFMA_F32_TFLOPS, "traffic": None}
+                            "frac": ach / PEAK_MFMA_F32_TFLOPS, "traffic": traffic}
                 else:
                     ach = k_bytes / (k_ms * 1e-3) / 1e9
                     roof = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                            "frac": ach / PEAK_HBM_GBS, "traffic": None}
+                            "frac": ach / PEAK_HBM_GBS, "traffic": traffic}
                 roof.update({"kernel": k_name, "kernel_ms": k_ms, "flops_per_launch": k_flops,
                              "algorithmic_bytes_per_launch": k_bytes,
-                             "arithmetic_intensity": k_flops / k_bytes, "ridge": ridge})
+                             "arithmetic_intensity": k_flops / k_bytes, "ridge": ridge,
+                             "tflops": k_flops / (k_ms * 1e-3) / 1e12})
             else:
                 gb = rows * SIDE * SIDE * in_dt.itemsize / 1e9
                 ach = gb / (k_ms * 1e-3)
