@@ -179,7 +179,7 @@ def main():
             kernels = []     # [name, ms, flops/row, bytes/row]
             for i, (nm, ms) in enumerate(stage_rows):
                 fl, by = per_layer[i] if (info.plan_kind == 1 and i < len(per_layer)) else (0, 0)
-                if kernels and ms < 1e-3 and info.plan_kind == 1 and i < len(per_layer):
+                if kernels and ms < 0.02 and "fused in the same persistent kernel" in kernels[-1][0] and info.plan_kind == 1 and i < len(per_layer):
                     kernels[-1][2] += fl
                     kernels[-1][3] += nodes_out_bytes[i] - nodes_out_bytes[i - 1]     # swap the intermediate output for the final one
                     kernels[-1][0] += " + " + nm.split(":")[0]

@@ -924,7 +924,14 @@ __global__ void __launch_bounds__(512) k_stage01p(StageParams P, StageParams Q) 
     };
     f32x4 v[NB];
     if (part < n_groups) fetch(part, v);
+    // two LDS tiles, used alternately: one barrier per tile group is enough (a wave that writes tile
+    // i+1 has passed barrier i, i.e. every wave has finished reading tile i-1, which shares its buffer)
+    const int buf_words = T * 16 * stride;
+    float* lds0 = lds;
+    int flip = 0;
     for (int grp = part; grp < n_groups; grp += P.tile_parts) {
+        lds = lds0 + flip * buf_words;
+        flip ^= 1;
 #pragma unroll
         for (int k = 0; k < NB; ++k)
             if (p_dst[k] >= 0) *(f32x4*)(lds + (p_dst[k] & 0xffffff)) = v[k];
@@ -1017,7 +1024,6 @@ __global__ void __launch_bounds__(512) k_stage01p(StageParams P, StageParams Q) 
                 for (int t = 0; t < T; ++t)
                     if (tile[t] < P.n_tiles) Q.out[((size_t)tile[t] * Q.nb_out + (size_t)n1 * Q.mto + mt) * 64 + lane] = y1[mt][t];
         }
-        __syncthreads();
     }
 }
 
@@ -1096,7 +1102,7 @@ StageFn pick_stage0(int mt1, int mt2, int T, int x_dtype) {
 // ---- the executor --------------------------------------------------------------------------------
 inline int q_of_row(int i) { return 4 * (i & 3) + (i >> 2); }  // tile row -> tile-local feature (involution)
 
-constexpr int kStage0ChunkCols = 256;   // columns of one sub-image staged per chunk (T = 4 tiles -> ~66 KiB LDS)
+constexpr int kStage0ChunkCols = 128;   // columns of one sub-image staged per chunk (T = 4 tiles -> ~66 KiB LDS)
 constexpr int kWeightLdsKiB = 64;       // target size of a node group's weights in LDS
 
 struct HostStage {
@@ -1416,15 +1422,16 @@ public:
                     StageParams Q = base_params(stages_[1], nullptr, cur);
                     StageFn2 fn = x_dtype == HG_U8 ? (StageFn2)k_stage01p<uint8_t>
                                   : x_dtype == HG_F32 ? (StageFn2)k_stage01p<float> : (StageFn2)k_stage01p<double>;
-                    const size_t lds2 = (size_t)2 * 16 * s.lds_stride * 4;
+                    const size_t lds2 = (size_t)2 * 2 * 16 * s.lds_stride * 4;   // two tiles of T = 2 batch tiles
+                    const int thr01 = 64 * std::max(1, (s.max_chunk_nodes + 1) / 2);   // one wave per pair of layer-0 nodes
                     const int groups2 = (n_tiles + 1) / 2;
                     int occ = 1;
                     {
-                        auto key = std::make_tuple((const void*)fn, 512, lds2);
+                        auto key = std::make_tuple((const void*)fn, thr01, lds2);
                         auto it = occ_.find(key);
                         if (it == occ_.end()) {
                             int nb = 0;
-                            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)fn, 512, lds2) != hipSuccess || nb < 1) nb = 1;
+                            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)fn, thr01, lds2) != hipSuccess || nb < 1) nb = 1;
                             occ_[key] = nb;
                             occ = nb;
                         } else {
@@ -1432,7 +1439,7 @@ public:
                         }
                     }
                     P.tile_parts = std::max(1, std::min(groups2, 256 * occ / std::max(1, P.n_chunks)));
-                    hipLaunchKernelGGL(fn, (unsigned)(P.n_chunks * P.tile_parts), 512, lds2, st, P, Q);
+                    hipLaunchKernelGGL(fn, (unsigned)(P.n_chunks * P.tile_parts), thr01, lds2, st, P, Q);
                     if (ev) {
                         HG_HIP(hipEventRecord(ev[e++], st));   // stage 0 (carries the fused time)
                         HG_HIP(hipEventRecord(ev[e++], st));   // stage 1 (fused: no launch of its own)
