@@ -1,0 +1,138 @@
+"""CPU: the stub-unpickler converter on synthetic pickles written under the module and
+class names the reference's SavedNetworks use (FaceDetectUpdated.py:57-68), protocol 2 like Python-2 files."""
+import pickle
+import sys
+import types
+
+import numpy as np
+import pytest
+
+from oracle import mdp_restate as oracle
+from pyfaceanalysis_amd import pickle_import
+from pyfaceanalysis_amd.blob import blob_to_flow, flow_to_blob
+from tests import helpers
+
+
+def _fake_modules():
+    """mdp / cuicuilco look-alikes: plain attribute bags with MDP's attribute names."""
+    mods = {}
+    for name in ("mdp", "mdp.nodes", "mdp.hinet", "mdp.linear_flows", "more_nodes", "gsfa_node", "igsfa_node",
+                 "nonlinear_expansion"):
+        mods[name] = types.ModuleType(name)
+
+    def mk(mod, cname):
+        cls = type(cname, (object,), {"__module__": mod})
+        setattr(mods[mod], cname, cls)
+        return cls
+
+    C = {c: mk(m, c) for m, c in [("mdp.nodes", "PCANode"), ("mdp.nodes", "WhiteningNode"), ("mdp.nodes", "SFANode"),
+                                  ("gsfa_node", "GSFANode"), ("mdp.nodes", "LinearRegressionNode"),
+                                  ("more_nodes", "GeneralExpansionNode"), ("more_nodes", "PInvSwitchboard"),
+                                  ("mdp.hinet", "Switchboard"), ("mdp.hinet", "Rectangular2dSwitchboard"),
+                                  ("mdp.hinet", "Layer"), ("mdp.hinet", "CloneLayer"), ("mdp.hinet", "FlowNode"),
+                                  ("igsfa_node", "iGSFANode"), ("mdp.linear_flows", "Flow"), ("more_nodes", "HeadNode"),
+                                  ("more_nodes", "MysteryNode")]}
+    for fname in ("identity", "unsigned_08expo", "signed_08expo", "QT", "pair_prodsadj1_ex", "fancy_unknown_exp"):
+        def f(x):
+            return x
+        f.__name__ = f.__qualname__ = fname
+        f.__module__ = "nonlinear_expansion"
+        setattr(mods["nonlinear_expansion"], fname, f)
+    return mods, C
+
+
+def _to_fake(node, mods, C):
+    """description object -> fake MDP object graph (the inverse of what the importer does)."""
+    name = type(node).__name__
+    E = mods["nonlinear_expansion"]
+
+    def bag(cls, **kw):
+        o = cls()
+        o.__dict__.update(kw)
+        return o
+    io = dict(_input_dim=node.input_dim, _output_dim=node.output_dim, _dtype=np.dtype("float64"))
+    if name in ("PCANode", "WhiteningNode"):
+        v = np.hstack([node.v, np.zeros((node.input_dim, 2))])        # MDP keeps more columns than output_dim
+        return bag(C[name], avg=node.avg, v=v, **io)
+    if name in ("SFANode", "GSFANode"):
+        return bag(C[name], avg=node.avg, sf=node.sf, _bias=node._bias, **io)
+    if name == "LinearRegressionNode":
+        return bag(C[name], beta=node.beta, **io)
+    if name == "GeneralExpansionNode":
+        fn = {"identity": E.identity, "unsigned_08expo": E.unsigned_08expo, "signed_08expo": E.signed_08expo,
+              "QT": E.QT, "pair_prodsadj1_ex": E.pair_prodsadj1_ex}
+        return bag(C[name], funcs=[fn[f.__name__] for f in node.funcs], **io)
+    if name in ("Switchboard", "Rectangular2dSwitchboard", "PInvSwitchboard"):
+        return bag(C[name], connections=node.connections, **io)
+    if name == "CloneLayer":
+        inner = _to_fake(node.node, mods, C)
+        return bag(C[name], node=inner, nodes=(inner,) * len(node.nodes), **io)
+    if name == "Layer":
+        return bag(C[name], nodes=[_to_fake(n, mods, C) for n in node.nodes], **io)
+    if name == "FlowNode":
+        return bag(C[name], _flow=bag(C["Flow"], flow=[_to_fake(n, mods, C) for n in node.flow]), **io)
+    if name == "iGSFANode":
+        return bag(C[name], x_mean=node.x_mean, exp_node=_to_fake(node.exp_node, mods, C), sfa_node=_to_fake(node.sfa_node, mods, C),
+                   pca_node=_to_fake(node.pca_node, mods, C), lr_node=_to_fake(node.lr_node, mods, C),
+                   magn_n_sfa_x=node.magn_n_sfa_x, num_sfa_features_preserved=node.num_sfa_features_preserved,
+                   reconstruct_with_sfa=True, **io)
+    raise TypeError(name)
+
+
+def _dump(tmp_path, nodes, mods, C, as_tuple=False):
+    flow = C["Flow"]()
+    flow.flow = [_to_fake(n, mods, C) for n in nodes]
+    saved = dict(sys.modules)
+    sys.modules.update(mods)
+    try:
+        data = pickle.dumps((flow, "extra", 1) if as_tuple else flow, protocol=2)
+    finally:
+        for k in mods:
+            if k in saved:
+                sys.modules[k] = saved[k]
+            else:
+                sys.modules.pop(k, None)
+    p = tmp_path / "flow.pckl"
+    p.write_bytes(data)
+    return str(p)
+
+
+@pytest.mark.parametrize("case", ["trained", "igsfa", "overlap", "linear"])
+def test_roundtrip_through_fake_mdp_pickle(tmp_path, nets, case):
+    nodes = {"trained": lambda: nets("T5L-16"), "igsfa": lambda: nets("T5L-16", node_kind="igsfa"),
+             "overlap": lambda: helpers.overlapping_net(2), "linear": lambda: helpers.linear_net(2)}[case]()
+    if case == "overlap":     # sel_exp has no cuicuilco function name here: use plain functions
+        from pyfaceanalysis_amd import nodes as N
+        nodes = helpers.overlapping_net(2, funcs=[N.identity, N.unsigned_08expo, N.signed_08expo])
+    mods, C = _fake_modules()
+    path = _dump(tmp_path, nodes, mods, C, as_tuple=(case == "trained"))
+    assert "mdp" not in sys.modules and "more_nodes" not in sys.modules          # really no mdp around
+    got = pickle_import.load_flow_pickle(path)
+    x = np.random.default_rng(0).normal(size=(9, nodes[0].input_dim)) * 3 + 100
+    assert np.array_equal(oracle.execute_flow(got, x), oracle.execute_flow(nodes, x))
+    assert flow_to_blob(got) == flow_to_blob(blob_to_flow(pickle_import.pickle_to_blob(path)))
+
+
+def test_unknown_classes_fail_loudly(tmp_path):
+    mods, C = _fake_modules()
+    flow = C["Flow"]()
+    bad = C["MysteryNode"]()
+    bad.__dict__.update(_input_dim=4, _output_dim=4)
+    flow.flow = [bad]
+    sys.modules.update(mods)
+    try:
+        data = pickle.dumps(flow, protocol=2)
+        exp = C["GeneralExpansionNode"]()
+        exp.__dict__.update(_input_dim=3, _output_dim=3, funcs=[mods["nonlinear_expansion"].fancy_unknown_exp])
+        flow2 = C["Flow"]()
+        flow2.flow = [exp]
+        data2 = pickle.dumps(flow2, protocol=2)
+    finally:
+        for k in mods:
+            sys.modules.pop(k, None)
+    (tmp_path / "a.pckl").write_bytes(data)
+    (tmp_path / "b.pckl").write_bytes(data2)
+    with pytest.raises(TypeError, match="unsupported node class"):
+        pickle_import.load_flow_pickle(str(tmp_path / "a.pckl"))
+    with pytest.raises(TypeError, match="unsupported expansion function"):
+        pickle_import.load_flow_pickle(str(tmp_path / "b.pckl"))
