@@ -267,6 +267,7 @@ struct StageParams {
     const void* x;
     int64_t ldx, n_rows;
     int32_t lds_stride, nk_last, vec4, contig4;
+    unsigned long long* stamps;   // diagnostic build only (HIGSFA_STAMP): per-wave cycle stamps
 };
 
 __device__ __forceinline__ float pow_abs(float v, float p) {
@@ -369,11 +370,17 @@ __device__ __forceinline__ void node_tail(const StageParams& P, WP wA2, BP b2, i
             if (tile[t] < P.n_tiles) P.out[((size_t)tile[t] * P.nb_out + out_blk + mt) * 64 + lane] = y[mt][t];
 }
 
+__device__ __forceinline__ unsigned long long stamp_now() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+
 // Stages > 0.  A workgroup of NW waves owns NW*T batch tiles and walks a range of nodes; the
 // weights of `nodes_per_group` nodes at a time are copied once into LDS and shared by all waves
 // (A fragments by ds_read_b128); activation fragments come straight from HBM/L2 with one 16 B/lane
 // coalesced load per K-block and tile, prefetched one K-block ahead.
-template <int MT1, int MT2, int T>
+template <int MT1, int MT2, int T, bool STAMP = false>
 __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
     extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
     const int tid = threadIdx.x, nthr = blockDim.x;
@@ -390,8 +397,17 @@ __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
     float* sb = (float*)(smem + (size_t)npg * P.node_blocks * 64);
     int2* stab = (int2*)(sb + npg * P.bias_floats);
 
+    unsigned long long t_copy = 0, t_g1 = 0, t_tail = 0, t_all0 = 0;
+    int n_it = 0;
+    unsigned long long rt0 = 0;
+    if (STAMP) {
+        t_all0 = stamp_now();
+        rt0 = __builtin_amdgcn_s_memrealtime();
+    }
     for (int g0 = n_begin; g0 < n_end; g0 += npg) {
         const int gn = min(npg, n_end - g0);
+        unsigned long long tc0 = 0;
+        if (STAMP) tc0 = stamp_now();
         __syncthreads();
         {   // cooperative copy of the group's weights, 4 x 16 B in flight per thread
             const f32x4* src = P.afrag + (size_t)g0 * P.node_blocks * 64;
@@ -416,6 +432,7 @@ __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
         // activation fragments form ONE prefetch stream across K-blocks, nodes and tile groups:
         // while block i is multiplied, block i+1 — possibly the first block of the next node or of
         // the next tile group — is already in flight, so no visit starts with an exposed load.
+        if (STAMP) t_copy += stamp_now() - tc0;
         int tile[T];
         uint32_t trow[T], trow_nx[T];   // first block of the tile's row in the input activation
 #pragma unroll
@@ -453,6 +470,8 @@ __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
 #pragma unroll
                     for (int t = 0; t < T; ++t) z[mt][t] = bb;
                 }
+                unsigned long long ts0 = 0, ts1 = 0;
+                if (STAMP) ts0 = stamp_now();
                 for (int kbi = 0; kbi < P.kb1; ++kbi) {
                     const bool in_node = kbi + 1 < P.kb1;
                     const bool in_group = in_node || ln + 1 < gn;
@@ -466,7 +485,14 @@ __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
                     for (int t = 0; t < T; ++t) bf[t] = bfn[t];
                     nk = nkn;
                 }
+                if (STAMP) ts1 = stamp_now();
                 node_tail<MT1, MT2, T>(P, wA2, b1 + MT1 * 16, (g0 + ln) * P.mto, z, tile, lane);
+                if (STAMP) {
+                    unsigned long long ts2 = stamp_now();
+                    t_g1 += ts1 - ts0;
+                    t_tail += ts2 - ts1;
+                    ++n_it;
+                }
             }
             if (!has_next) break;
 #pragma unroll
@@ -475,6 +501,15 @@ __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
                 trow[t] = trow_nx[t];
             }
         }
+    }
+    if (STAMP && lane == 0 && P.stamps) {
+        unsigned long long* o = P.stamps + ((size_t)blockIdx.x * 8 + wave) * 6;
+        o[5] = __builtin_amdgcn_s_memrealtime() - rt0;
+        o[0] = t_copy;
+        o[1] = t_g1;
+        o[2] = t_tail;
+        o[3] = stamp_now() - t_all0;
+        o[4] = (unsigned long long)n_it;
     }
 }
 
@@ -1363,14 +1398,52 @@ public:
         cap_rows_ = std::max(cap_rows_, tiles * 16);
     }
 
+    // Experiment (HIGSFA_SPLIT=k): cut large batches into k row ranges that run the whole stage
+    // sequence on separate internal streams, hoping the launch ramp / drain of one range's kernels
+    // overlaps the steady state of the other's.  Ranges use disjoint slices of the workspace; the
+    // caller's stream waits for all of them.
     void run(const void* x, int x_dtype, int64_t n, int64_t ldx, void* y, int y_dtype, int64_t y_cols, int64_t ldy,
              hipStream_t st, hipEvent_t* ev) override {
         if (n > cap_rows_) reserve(n);
+        // measured on MI355X at N = 4096: split 1 -> 0.656 ms, 2 -> 0.691, 3 -> 0.825, 4 -> 0.780: the
+        // persistent kernels are sized to fill the chip, two of them only compete.  Off by default.
+        int split = 1;
+        if (const char* sp = getenv("HIGSFA_SPLIT")) split = std::max(1, std::min(4, atoi(sp)));
+        if (ev || n < 2048 || split == 1) {
+            run_range(x, x_dtype, n, ldx, y, y_dtype, y_cols, ldy, st, ev, (f32x4*)bufA_.p, (f32x4*)bufB_.p);
+            return;
+        }
+        while ((int)streams_.size() < split) {
+            hipStream_t s2;
+            HG_HIP(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+            streams_.push_back(s2);
+            hipEvent_t e2;
+            HG_HIP(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+            join_.push_back(e2);
+        }
+        if (!fork_) HG_HIP(hipEventCreateWithFlags(&fork_, hipEventDisableTiming));
+        HG_HIP(hipEventRecord(fork_, st));
+        const int64_t per = ((n + split - 1) / split + 31) / 32 * 32;
+        const size_t xs = dtype_size(x_dtype), ys = dtype_size(y_dtype);
+        for (int k = 0; k < split; ++k) {
+            const int64_t r0 = (int64_t)k * per, m = std::min(per, n - r0);
+            if (m <= 0) break;
+            const size_t woff = (size_t)(r0 / 16) * max_nb_ * 64;   // f32x4 elements (1 KiB blocks)
+            HG_HIP(hipStreamWaitEvent(streams_[k], fork_, 0));
+            run_range((const char*)x + (size_t)r0 * ldx * xs, x_dtype, m, ldx, (char*)y + (size_t)r0 * ldy * ys, y_dtype, y_cols, ldy,
+                      streams_[k], nullptr, (f32x4*)bufA_.p + woff, (f32x4*)bufB_.p + woff);
+            HG_HIP(hipEventRecord(join_[k], streams_[k]));
+            HG_HIP(hipStreamWaitEvent(st, join_[k], 0));
+        }
+    }
+
+    void run_range(const void* x, int x_dtype, int64_t n, int64_t ldx, void* y, int y_dtype, int64_t y_cols, int64_t ldy,
+                   hipStream_t st, hipEvent_t* ev, f32x4* bufA, f32x4* bufB) {
         const int n_tiles = (int)((n + 15) / 16);
         int e = 0;
         if (ev) HG_HIP(hipEventRecord(ev[e++], st));
-        f32x4* cur = (f32x4*)bufA_.p;
-        f32x4* nxt = (f32x4*)bufB_.p;
+        f32x4* cur = bufA;
+        f32x4* nxt = bufB;
         for (size_t si = 0; si < stages_.size(); ++si) {
             HostStage& s = stages_[si];
             auto base_params = [&](HostStage& hs, const f32x4* in, f32x4* out) {
@@ -1521,8 +1594,28 @@ public:
                 if (blocks > 0x7fffffffll) fail(HG_ERR_ARG, "batch too large");
                 size_t lds_bytes = (size_t)npg * s.node_blocks * 1024 + (size_t)npg * s.bias_floats * 4 + (size_t)npg * s.kb1 * 8;
                 StageFn fn = pick_stage(s.mt1, s.mt2, T);
+                const char* stamp_env = getenv("HIGSFA_STAMP");
+                if (stamp_env && atoi(stamp_env) == (int)si && s.mt1 == 4 && s.mt2 == 4 && T == 2) {
+                    // diagnostic instantiation with s_memtime stamps (never used in timed runs)
+                    fn = k_stage<4, 4, 2, true>;
+                    stamp_buf_.alloc((size_t)blocks * 8 * 6 * 8);
+                    HG_HIP(hipMemsetAsync(stamp_buf_.p, 0, stamp_buf_.bytes, st));
+                    P.stamps = (unsigned long long*)stamp_buf_.p;
+                    stamp_blocks_ = (int)blocks;
+                }
                 set_lds_limit(fn, lds_bytes);
                 hipLaunchKernelGGL(fn, (unsigned)blocks, nw * 64, lds_bytes, st, P);
+                if (P.stamps) {
+                    HG_HIP(hipStreamSynchronize(st));
+                    std::vector<unsigned long long> h((size_t)stamp_blocks_ * 8 * 6);
+                    HG_HIP(hipMemcpy(h.data(), stamp_buf_.p, h.size() * 8, hipMemcpyDeviceToHost));
+                    double c = 0, g1 = 0, tl = 0, all = 0, it = 0, nwv = 0, rt = 0;
+                    for (size_t i = 0; i < h.size(); i += 6)
+                        if (h[i + 3]) { c += h[i]; g1 += h[i + 1]; tl += h[i + 2]; all += h[i + 3]; it += h[i + 4]; rt += h[i + 5]; nwv += 1; }
+                    fprintf(stderr, "[stamp stage %d] in-kernel clock %.0f MHz, wave lifetime %.1f us\n", (int)si, all / rt * 100.0, rt / nwv / 100.0);
+                    fprintf(stderr, "[stamp stage %d] waves %.0f  avg cycles/wave: total %.0f  copy+barrier %.0f  gemm1 %.0f  tail %.0f  node-iterations %.1f  (per iteration: gemm1 %.0f tail %.0f)\n",
+                            (int)si, nwv, all / nwv, c / nwv, g1 / nwv, tl / nwv, it / nwv, g1 / it, tl / it);
+                }
             }
             std::swap(cur, nxt);
             if (ev) HG_HIP(hipEventRecord(ev[e++], st));
@@ -1542,6 +1635,12 @@ public:
     }
 
     void release() override {
+        for (auto s2 : streams_) (void)hipStreamDestroy(s2);
+        for (auto e2 : join_) (void)hipEventDestroy(e2);
+        if (fork_) (void)hipEventDestroy(fork_);
+        streams_.clear();
+        join_.clear();
+        fork_ = nullptr;
         bufA_.free();
         bufB_.free();
         d_col_base_.free();
@@ -1700,7 +1799,11 @@ private:
     bool s0_transpose_ = false, fuse01_ = false;
     std::vector<HostStage> stages_;
     std::vector<int32_t> col_base_;
-    DevBuf d_col_base_, bufA_, bufB_;
+    DevBuf d_col_base_, bufA_, bufB_, stamp_buf_;
+    std::vector<hipStream_t> streams_;
+    std::vector<hipEvent_t> join_;
+    hipEvent_t fork_ = nullptr;
+    int stamp_blocks_ = 0;
     std::map<const void*, size_t> lds_set_;
     std::map<std::tuple<const void*, int, size_t>, int> occ_;
     int max_nb_ = 0;
