@@ -67,6 +67,8 @@ def main():
     ap.add_argument("--input-dtype", default="float32", choices=["float32", "uint8", "float64"])
     ap.add_argument("--generic", action="store_true", help="force the generic plan (diagnostic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--node-kind", default="pca_exp_sfa", choices=["pca_exp_sfa", "igsfa"],
+                    help="node type of the synthetic 11-layer net (default: the BASELINE.md workload)")
     args = ap.parse_args()
 
     import torch
@@ -92,11 +94,11 @@ def main():
     # --- model: rank 0 builds (and caches) the net, the others load the cached blob
     if rank == 0:
         build()
-        blob, nodes = synth.cached_preset_blob(PRESET)
+        blob, nodes = synth.cached_preset_blob(PRESET, node_kind=args.node_kind)
     if world > 1:
         dist.barrier()
     if rank != 0:
-        blob, nodes = synth.cached_preset_blob(PRESET)
+        blob, nodes = synth.cached_preset_blob(PRESET, node_kind=args.node_kind)
     flow = Flow.from_blob(blob, device=local_rank, output_dtype=np.float32, force_generic=args.generic)
     info = flow.info()
     rows = args.rows
@@ -227,7 +229,7 @@ def main():
             "value": value, "unit": "sub-images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: U11L-128 (11-layer net, trained random-init weights), "
+            "config": {"workload": "configs[1]: U11L-128 (11-layer net, " + ("iGSFA nodes, " if args.node_kind == "igsfa" else "") + "trained random-init weights), "
                                    "%d synthetic 128x128 sub-images per GPU per step, %s input resident in HBM, "
                                    "first %d slow features out%s" % (rows, in_dt.name, N_COLS,
                                                                      ", RCCL all-gather" if world > 1 else ""),

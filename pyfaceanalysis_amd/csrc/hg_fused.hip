@@ -73,6 +73,12 @@ struct FNode {
     Aff A1, A2;
     bool has_exp = false;
     std::vector<ExpFunc> funcs;
+    // iGSFA node: x0 = x - mean; s = sfa(expand(x0)) (scale folded in);
+    // r = x0 - lr(s); q = pca(r); y = [s, q]
+    bool is_ig = false, ig_has_lr = false;
+    int ig_k = 0;
+    std::vector<double> ig_mean;
+    Aff ig_sfa, ig_lr, ig_pca;
 };
 
 struct FStage {
@@ -86,7 +92,8 @@ typedef std::vector<const TNode*> LeafSeq;
 bool flatten_leafs(const TNode& n, LeafSeq& s, std::string& why) {
     switch (n.kind) {
         case K_AFFINE:
-        case K_EXPANSION: s.push_back(&n); return true;
+        case K_EXPANSION:
+        case K_IGSFA: s.push_back(&n); return true;
         case K_IDENTITY: return true;
         case K_FLOWNODE:
         case K_FLOW:
@@ -126,6 +133,33 @@ bool canon(const ChainT& c, int in_off, FNode& fn, std::string& why) {
     fn.in_off = in_off;
     fn.in_dim = c.in_dim;
     fn.out_dim = c.out_dim;
+    for (const TNode* l : c.seq)
+        if (l->kind == K_IGSFA) {
+            if (c.seq.size() != 1) { why = "iGSFA node combined with other nodes in one chain"; return false; }
+            if (l->sfa->out_dim != l->aux) { why = "iGSFA node whose sfa_node has more outputs than it preserves"; return false; }
+            if (l->in_dim > 128 || l->out_dim > 16 * kMaxMT) { why = "iGSFA node with more than 128 inputs or 64 outputs"; return false; }
+            fn.is_ig = true;
+            fn.ig_k = (int)l->aux;
+            fn.ig_mean = l->x_mean;
+            fn.ig_sfa = aff_of(*l->sfa);
+            for (int r = 0; r < fn.ig_sfa.in; ++r)
+                for (int cc = 0; cc < fn.ig_sfa.out; ++cc) fn.ig_sfa.W[(size_t)r * fn.ig_sfa.out + cc] *= l->magn[cc];
+            {   // ((e - a) W + b) * magn = (e - a)(W magn) + b magn
+                for (int cc = 0; cc < fn.ig_sfa.out; ++cc) fn.ig_sfa.b[cc] *= l->magn[cc];
+            }
+            fn.ig_has_lr = (bool)l->lr;
+            if (l->lr) fn.ig_lr = aff_of(*l->lr);
+            fn.ig_pca = aff_of(*l->pca);
+            if (l->exp_node) {
+                for (const ExpFunc& f : l->exp_node->funcs)
+                    if (f.kind > E_SIGNED_POW) { why = "expansion with cross-column products (QT / pair products)"; return false; }
+                fn.funcs = l->exp_node->funcs;
+            } else {
+                fn.funcs = {ExpFunc{E_IDENTITY, 0, 0, 1.0}};
+            }
+            fn.has_exp = true;
+            return true;
+        }
     int phase = 0;  // 0: before A1, 1: in A1, 2: after E, 3: in A2
     for (const TNode* l : c.seq) {
         if (l->kind == K_AFFINE) {
@@ -210,10 +244,10 @@ bool build_stages(const TNode& root, std::vector<FStage>& stages, std::string& w
             // merging [A][E][A] + another [A ...] is fine (folds); anything after A2 with an expansion is not
             if (merged)
                 for (size_t k = 0; k < chains.size() && merged; ++k) {
-                    int n_exp = 0;
-                    for (auto* l : group[k].seq) n_exp += l->kind == K_EXPANSION;
-                    for (auto* l : chains[k].seq) n_exp += l->kind == K_EXPANSION;
-                    if (n_exp > 1) merged = false;
+                    int n_exp = 0, n_ig = 0;
+                    for (auto* l : group[k].seq) { n_exp += l->kind == K_EXPANSION; n_ig += l->kind == K_IGSFA; }
+                    for (auto* l : chains[k].seq) { n_exp += l->kind == K_EXPANSION; n_ig += l->kind == K_IGSFA; }
+                    if (n_exp > 1 || n_ig > 0) merged = false;
                 }
             if (merged)
                 for (size_t k = 0; k < chains.size(); ++k) {
@@ -267,6 +301,7 @@ struct StageParams {
     const void* x;
     int64_t ldx, n_rows;
     int32_t lds_stride, nk_last, vec4, contig4;
+    int32_t ig_has_lr;
     unsigned long long* stamps;   // diagnostic build only (HIGSFA_STAMP): per-wave cycle stamps
 };
 
@@ -1062,6 +1097,158 @@ __global__ void __launch_bounds__(512) k_stage01p(StageParams P, StageParams Q) 
     }
 }
 
+// Row-major input -> fragment order (used in front of a first layer of iGSFA nodes, whose kernel
+// reads fragment-order blocks like every later layer).  One wave per (batch tile, block): lane (g, j)
+// gathers the four columns of its four k-steps for sub-image j.
+template <typename XT>
+__global__ void __launch_bounds__(256) k_im2frag(const XT* __restrict__ x, int64_t ldx, int64_t n_rows, int n_tiles, int nb,
+                                                 const int32_t* __restrict__ gcol, f32x4* __restrict__ out) {
+    const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+    const int64_t wid = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (wid >= (int64_t)n_tiles * nb) return;
+    const int tile = (int)(wid / nb), blk = (int)(wid - (int64_t)tile * nb);
+    const int64_t row = (int64_t)tile * 16 + j;
+    const i32x4 c = *(const i32x4*)(gcol + (size_t)blk * 16 + g * 4);
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (row < n_rows) {
+        const XT* xr = x + row * ldx;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (c[r] >= 0) v[r] = (float)xr[c[r]];
+    }
+    out[(size_t)wid * 64 + lane] = v;
+}
+
+// A layer of iGSFA nodes.  Same workgroup structure as k_stage (node
+// weights once into LDS, persistent sweep over tile groups), three chained GEMMs per node, all
+// operands in registers:
+//   x0[kb] = input fragments - mean                                   (K-blocks of the node input)
+//   y[ms] += W1[fi][kb][ms] * f_fi(x0[kb])          s = scaled slow features (rows of y tiles < MS)
+//   x0[kb] = x0[kb] + bias_r[kb] + W2[kb][ms] * y[ms]                 r = x0 - lr(s): the input fragment
+//                                                                     IS the C operand (same layout)
+//   y[mo] += W3[kb][mo] * x0[kb]                    q = pca(r) lands in the remaining rows of y
+// Output tiles hold [s, q] in the caller's column order.
+template <int MS, int MO, int T>
+__global__ void __launch_bounds__(512, 2) k_igsfa(StageParams P) {
+    extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
+    constexpr int KBM = 8;   // K-blocks of a node input (<= 128 inputs)
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, nw = nthr >> 6, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int node = blockIdx.x % P.n_nodes, part = blockIdx.x / P.n_nodes;
+    float* sb = (float*)(smem + (size_t)P.node_blocks * 64);
+    int2* stab = (int2*)(sb + P.bias_floats);
+    {
+        const f32x4* src = P.afrag + (size_t)node * P.node_blocks * 64;
+        const int nvec = P.node_blocks * 64;
+        int i = tid;
+        for (; i + 3 * nthr < nvec; i += 4 * nthr) {
+            f32x4 v0 = src[i], v1 = src[i + nthr], v2 = src[i + 2 * nthr], v3 = src[i + 3 * nthr];
+            smem[i] = v0;
+            smem[i + nthr] = v1;
+            smem[i + 2 * nthr] = v2;
+            smem[i + 3 * nthr] = v3;
+        }
+        for (; i < nvec; i += nthr) smem[i] = src[i];
+        const float* bsrc = P.bias + (size_t)node * P.bias_floats;
+        for (int k = tid; k < P.bias_floats; k += nthr) sb[k] = bsrc[k];
+        const int2* tsrc = P.kb1tab + (size_t)node * P.kb1;
+        for (int k = tid; k < P.kb1; k += nthr) stab[k] = tsrc[k];
+    }
+    __syncthreads();
+    const int kb1 = P.kb1, nf = P.nf;
+    const f32x4* w1 = smem + lane;                                  // [fi][kb][ms]
+    const f32x4* w2 = w1 + (size_t)nf * kb1 * MS * 64;              // [kb][ms]
+    const f32x4* w3 = w2 + (size_t)kb1 * MS * 64;                   // [kb][mo]
+    const float* by = sb;                                           // [MO][16]
+    const float* br = sb + MO * 16;                                 // [kb][16]
+    const float* mu = br + kb1 * 16;                                // [kb][16]
+    for (int grp = part; grp < P.tile_groups; grp += P.tile_parts) {
+        int tile[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) tile[t] = (grp * nw + wave) * T + t;
+        if (tile[0] >= P.n_tiles) break;
+        f32x4 x0[KBM][T];
+        int nk1[KBM];
+#pragma unroll
+        for (int kb = 0; kb < KBM; ++kb) {
+            nk1[kb] = 0;
+            if (kb < kb1) {
+                const int2 e = stab[kb];
+                const int sbk = __builtin_amdgcn_readfirstlane(e.x);
+                nk1[kb] = __builtin_amdgcn_readfirstlane(e.y);
+                const f32x4 m = *(const f32x4*)(mu + kb * 16 + g * 4);
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const int tl = tile[t] < P.n_tiles ? tile[t] : tile[0];
+                    x0[kb][t] = P.in[((size_t)tl * P.nb_in + sbk) * 64 + lane] - m;
+                }
+            }
+        }
+        f32x4 y[MO][T];
+#pragma unroll
+        for (int mo = 0; mo < MO; ++mo) {
+            const f32x4 bb = *(const f32x4*)(by + mo * 16 + g * 4);
+#pragma unroll
+            for (int t = 0; t < T; ++t) y[mo][t] = bb;
+        }
+        // G1: slow features from the expanded input
+        for (int fi = 0; fi < nf; ++fi) {
+            const int fk = (P.funcp >> (4 * fi)) & 15;
+            const float ex = P.expo[fi];
+#pragma unroll
+            for (int kb = 0; kb < KBM; ++kb) {
+                if (kb >= kb1) continue;
+                f32x4 e[T];
+#pragma unroll
+                for (int t = 0; t < T; ++t) e[t] = apply_func(fk, ex, x0[kb][t]);
+                const f32x4* wp = w1 + ((size_t)(fi * kb1 + kb) * MS) * 64;
+#pragma unroll
+                for (int ms = 0; ms < MS; ++ms) {      // only the tiles that hold slow features
+                    const f32x4 a = wp[ms * 64];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (r < nk1[kb]) {
+#pragma unroll
+                            for (int t = 0; t < T; ++t) y[ms][t] = MFMA16(a[r], e[t][r], y[ms][t]);
+                        }
+                }
+            }
+        }
+        // G2: residual r = x0 - lr(s), accumulated into the input fragments
+        if (P.ig_has_lr) {
+#pragma unroll
+            for (int kb = 0; kb < KBM; ++kb) {
+                if (kb >= kb1) continue;
+                const f32x4 bb = *(const f32x4*)(br + kb * 16 + g * 4);
+#pragma unroll
+                for (int t = 0; t < T; ++t) x0[kb][t] += bb;
+#pragma unroll
+                for (int ms = 0; ms < MS; ++ms) {
+                    const f32x4 a = w2[((size_t)kb * MS + ms) * 64];
+                    const int nks = (P.nk2p[0] >> (4 * ms)) & 15;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (r < nks) {
+#pragma unroll
+                            for (int t = 0; t < T; ++t) x0[kb][t] = MFMA16(a[r], y[ms][t][r], x0[kb][t]);
+                        }
+                }
+            }
+        }
+        // G3: q = pca(r) into the remaining rows of the output tiles
+#pragma unroll
+        for (int kb = 0; kb < KBM; ++kb) {
+            if (kb >= kb1) continue;
+            gemm_block<MO, T>(w3 + ((size_t)kb * MO) * 64, x0[kb], y, nk1[kb]);
+        }
+#pragma unroll
+        for (int mo = 0; mo < MO; ++mo)
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+                if (tile[t] < P.n_tiles) P.out[((size_t)tile[t] * P.nb_out + (size_t)node * MO + mo) * 64 + lane] = y[mo][t];
+    }
+}
+
 // Fragment order -> caller's row-major y (first y_cols columns).
 template <typename YT>
 __global__ void k_unpack(const float* __restrict__ act, int nb, const int32_t* __restrict__ col_base, YT* __restrict__ y,
@@ -1134,6 +1321,26 @@ StageFn pick_stage0(int mt1, int mt2, int T, int x_dtype) {
     }
 }
 
+template <int MS, int MO>
+StageFn pick_igsfa_t(int T) {
+    if (T == 2) return k_igsfa<MS, MO, 2>;
+    return k_igsfa<MS, MO, 1>;
+}
+StageFn pick_igsfa(int ms, int mo, int T) {   // ms <= mo (the slow features are a prefix of the output)
+    switch (ms * 10 + mo) {
+        case 11: return pick_igsfa_t<1, 1>(T);
+        case 12: return pick_igsfa_t<1, 2>(T);
+        case 13: return pick_igsfa_t<1, 3>(T);
+        case 14: return pick_igsfa_t<1, 4>(T);
+        case 22: return pick_igsfa_t<2, 2>(T);
+        case 23: return pick_igsfa_t<2, 3>(T);
+        case 24: return pick_igsfa_t<2, 4>(T);
+        case 33: return pick_igsfa_t<3, 3>(T);
+        case 34: return pick_igsfa_t<3, 4>(T);
+        default: return pick_igsfa_t<4, 4>(T);
+    }
+}
+
 // ---- the executor --------------------------------------------------------------------------------
 inline int q_of_row(int i) { return 4 * (i & 3) + (i >> 2); }  // tile row -> tile-local feature (involution)
 
@@ -1154,6 +1361,12 @@ struct HostStage {
     std::vector<int32_t> piece_col, koff;
     std::vector<float> kmean;
     int lds_stride = 0, max_chunk_nodes = 0, max_chunk_pieces = 0;
+    int kind = 0;            // 0: affine-expansion-affine layer, 1: row-major -> fragment gather, 2: iGSFA layer
+    bool from_x = false;     // reads the caller's row-major matrix
+    bool ig_has_lr = false;
+    int ig_nks[kMaxMT] = {};  // k-steps of each slow-feature tile
+    std::vector<int32_t> gcol;
+    DevBuf d_gcol;
     int64_t mfma_per_tile = 0;
     std::string name;
     DevBuf d_afrag, d_bias, d_kb1tab, d_chunks, d_runs, d_piece, d_koff, d_kmean;
@@ -1166,8 +1379,15 @@ public:
         int prev_nb = 0;
         for (size_t si = 0; si < fs.size(); ++si) {
             FStage& st = fs[si];
+            if (st.nodes[0].is_ig) {
+                if (stages_.empty()) add_gather0(st, prev_blk, prev_q, prev_nb);
+                build_ig_stage(st, prev_blk, prev_q, prev_nb);
+                continue;
+            }
+            if (si > 0 && stages_.empty()) fail(HG_ERR_FORMAT, "internal: stage order");
             stages_.emplace_back();
             HostStage& hs = stages_.back();
+            hs.from_x = si == 0;
             const int n = (int)st.nodes.size();
             hs.n_nodes = n;
             hs.has_exp = st.nodes[0].has_exp;
@@ -1378,6 +1598,7 @@ public:
             s.d_afrag.upload(s.afrag.data(), s.afrag.size() * 4);
             s.d_bias.upload(s.bias.data(), s.bias.size() * 4);
             if (!s.kb1tab.empty()) s.d_kb1tab.upload(s.kb1tab.data(), s.kb1tab.size() * 4);
+            if (!s.gcol.empty()) s.d_gcol.upload(s.gcol.data(), s.gcol.size() * 4);
             if (!s.chunks.empty()) {
                 s.d_chunks.upload(s.chunks.data(), s.chunks.size() * sizeof(DChunk));
                 s.d_runs.upload(s.runs.data(), s.runs.size() * sizeof(DRun));
@@ -1471,7 +1692,37 @@ public:
                 return R;
             };
             StageParams P = base_params(s, cur, nxt);
-            if (si == 0) {
+            if (s.kind == 1) {        // row-major input -> fragment order
+                const int64_t waves = (int64_t)n_tiles * s.nb_out;
+                const unsigned grid = (unsigned)((waves + 3) / 4);
+                if (x_dtype == HG_U8)
+                    hipLaunchKernelGGL(k_im2frag<uint8_t>, grid, 256, 0, st, (const uint8_t*)x, ldx, n, n_tiles, s.nb_out, (const int32_t*)s.d_gcol.p, nxt);
+                else if (x_dtype == HG_F32)
+                    hipLaunchKernelGGL(k_im2frag<float>, grid, 256, 0, st, (const float*)x, ldx, n, n_tiles, s.nb_out, (const int32_t*)s.d_gcol.p, nxt);
+                else
+                    hipLaunchKernelGGL(k_im2frag<double>, grid, 256, 0, st, (const double*)x, ldx, n, n_tiles, s.nb_out, (const int32_t*)s.d_gcol.p, nxt);
+                std::swap(cur, nxt);
+                if (ev) HG_HIP(hipEventRecord(ev[e++], st));
+                continue;
+            }
+            if (s.kind == 2) {        // iGSFA layer
+                int nw = 8, T = 2;
+                while (nw > 1 && nw * T > n_tiles) nw >>= 1;
+                if (nw * T > n_tiles) T = 1;
+                P.ig_has_lr = s.ig_has_lr ? 1 : 0;
+                P.nk2p[0] = 0;
+                for (int ms = 0; ms < s.mt1; ++ms) P.nk2p[0] |= (uint32_t)s.ig_nks[ms] << (4 * ms);
+                P.tile_groups = (n_tiles + nw * T - 1) / (nw * T);
+                P.tile_parts = std::max(1, std::min(P.tile_groups, 512 / std::max(1, s.n_nodes)));
+                const size_t lds_bytes = (size_t)s.node_blocks * 1024 + (size_t)s.bias_floats * 4 + (size_t)s.kb1 * 8;
+                StageFn fn = pick_igsfa(s.mt1, s.mt2, T);
+                set_lds_limit(fn, lds_bytes);
+                hipLaunchKernelGGL(fn, (unsigned)(s.n_nodes * P.tile_parts), nw * 64, lds_bytes, st, P);
+                std::swap(cur, nxt);
+                if (ev) HG_HIP(hipEventRecord(ev[e++], st));
+                continue;
+            }
+            if (s.from_x) {
                 P.chunks = (const DChunk*)s.d_chunks.p;
                 P.runs = (const DRun*)s.d_runs.p;
                 P.piece_col = (const int2*)s.d_piece.p;
@@ -1646,7 +1897,7 @@ public:
         d_col_base_.free();
         for (auto& s : stages_) {
             s.d_afrag.free(); s.d_bias.free(); s.d_kb1tab.free(); s.d_chunks.free();
-            s.d_runs.free(); s.d_piece.free(); s.d_koff.free(); s.d_kmean.free();
+            s.d_runs.free(); s.d_piece.free(); s.d_koff.free(); s.d_kmean.free(); s.d_gcol.free();
         }
         cap_rows_ = 0;
     }
@@ -1776,12 +2027,206 @@ private:
         hs.vec_ok = vec_ok;
     }
 
+    // First layer of iGSFA nodes: a gather pseudo-stage turns the row-major input into fragment-order
+    // blocks (one block per node K-block), after which the iGSFA layer reads blocks like any other.
+    void add_gather0(FStage& st, std::vector<int32_t>& prev_blk, std::vector<int32_t>& prev_q, int& prev_nb) {
+        stages_.emplace_back();
+        HostStage& hs = stages_.back();
+        hs.kind = 1;
+        hs.from_x = true;
+        const int n = (int)st.nodes.size();
+        int KB = 0;
+        bool tr = true;
+        for (auto& nd : st.nodes) {
+            KB = std::max(KB, (nd.in_dim + 15) / 16);
+            for (int c = 0; c < nd.in_dim && tr; c += 4)
+                for (int r = 1; r < 4 && c + r < nd.in_dim; ++r)
+                    if (st.conn[nd.in_off + c + r] != st.conn[nd.in_off + c] + r) tr = false;
+            if (nd.in_dim % 4) tr = false;
+        }
+        hs.n_nodes = n;
+        hs.kb1 = KB;
+        hs.nb_out = n * KB;
+        hs.gcol.assign((size_t)n * KB * 16, -1);
+        const int in_w = (int)st.conn.size();
+        prev_blk.assign(in_w, 0);
+        prev_q.assign(in_w, 0);
+        for (int ni = 0; ni < n; ++ni) {
+            const FNode& nd = st.nodes[ni];
+            for (int c = 0; c < nd.in_dim; ++c) {
+                const int kb = c / 16, pp = c % 16;
+                const int q = tr ? 4 * (pp % 4) + pp / 4 : pp;     // slot q = 4r + g
+                hs.gcol[((size_t)ni * KB + kb) * 16 + (q & 3) * 4 + (q >> 2)] = st.conn[nd.in_off + c];
+                prev_blk[nd.in_off + c] = ni * KB + kb;
+                prev_q[nd.in_off + c] = q;
+            }
+        }
+        for (int i = 0; i < in_w; ++i) st.conn[i] = i;
+        prev_nb = hs.nb_out;
+        max_nb_ = std::max(max_nb_, hs.nb_out);
+        std::ostringstream os;
+        os << "fused gather: row-major input -> fragment order, " << n << " nodes x " << KB << " K-blocks";
+        hs.name = os.str();
+    }
+
+    void build_ig_stage(FStage& st, std::vector<int32_t>& prev_blk, std::vector<int32_t>& prev_q, int& prev_nb) {
+        stages_.emplace_back();
+        HostStage& hs = stages_.back();
+        hs.kind = 2;
+        hs.has_exp = true;
+        const int n = (int)st.nodes.size();
+        hs.n_nodes = n;
+        hs.funcs = st.nodes[0].funcs;
+        hs.nf = (int)hs.funcs.size();
+        hs.ig_has_lr = st.nodes[0].ig_has_lr;
+        hs.nb_in = prev_nb;
+        int k_max = 0, out_max = 0;
+        struct NodeK {
+            std::vector<int> src, nk, pos;   // per K-block: source block, k-steps; per slot: input position or -1
+        };
+        std::vector<NodeK> nks(n);
+        for (int ni = 0; ni < n; ++ni) {
+            FNode& nd = st.nodes[ni];
+            if (nd.ig_has_lr != hs.ig_has_lr) fail(HG_ERR_FORMAT, "fused: iGSFA nodes of one layer differ in reconstruct_with_sfa");
+            k_max = std::max(k_max, nd.ig_k);
+            out_max = std::max(out_max, nd.out_dim);
+            NodeK& K = nks[ni];
+            std::map<int, int> blk_index;
+            for (int c = 0; c < nd.in_dim; ++c) {
+                const int pc = st.conn[nd.in_off + c];
+                const int blk = prev_blk[pc], q = prev_q[pc];
+                auto it = blk_index.find(blk);
+                int kb;
+                if (it == blk_index.end()) {
+                    kb = (int)K.src.size();
+                    blk_index[blk] = kb;
+                    K.src.push_back(blk);
+                    K.nk.push_back(0);
+                    for (int qq = 0; qq < 16; ++qq) K.pos.push_back(-1);
+                } else {
+                    kb = it->second;
+                }
+                if (K.pos[kb * 16 + q] >= 0) fail(HG_ERR_FORMAT, "fused: iGSFA node reads one input column twice");
+                K.pos[kb * 16 + q] = c;
+                K.nk[kb] = std::max(K.nk[kb], q / 4 + 1);
+            }
+            hs.kb1 = std::max(hs.kb1, (int)K.src.size());
+        }
+        if (hs.kb1 > 8) fail(HG_ERR_FORMAT, "fused: iGSFA node input spans more than 8 source blocks");
+        const int KB = hs.kb1, MS = (k_max + 15) / 16, MO = (out_max + 15) / 16, nf = hs.nf;
+        hs.mt1 = MS;
+        hs.mt2 = MO;
+        hs.mto = MO;
+        for (int ms = 0; ms < MS; ++ms) hs.ig_nks[ms] = (std::min(16, k_max - 16 * ms) + 3) / 4;
+        hs.node_blocks = nf * KB * MS + KB * MS + KB * MO;
+        hs.bias_floats = MO * 16 + 2 * KB * 16;
+        hs.afrag.assign((size_t)n * hs.node_blocks * 256, 0.f);
+        hs.bias.assign((size_t)n * hs.bias_floats, 0.f);
+        hs.kb1tab.assign((size_t)n * KB * 2, 0);
+        std::vector<int32_t> cur_blk, cur_q;
+        for (int ni = 0; ni < n; ++ni) {
+            FNode& nd = st.nodes[ni];
+            NodeK& K = nks[ni];
+            const int d = nd.in_dim, k = nd.ig_k, Q = nd.ig_pca.out;
+            if (nd.ig_sfa.out != k || nd.ig_pca.in != d || k + Q != nd.out_dim) fail(HG_ERR_DIM, "fused: iGSFA node dimensions");
+            std::vector<int> foff(nf), used(nf);
+            int eo = 0;
+            for (int fi = 0; fi < nf; ++fi) {
+                foff[fi] = eo;
+                used[fi] = nd.funcs[fi].used(d);
+                eo += nd.funcs[fi].out_dim(d);
+            }
+            if (eo != nd.ig_sfa.in) fail(HG_ERR_DIM, "fused: iGSFA expansion width != sfa input_dim");
+            float* wn = hs.afrag.data() + (size_t)ni * hs.node_blocks * 256;
+            float* w1 = wn;
+            float* w2 = w1 + (size_t)nf * KB * MS * 256;
+            float* w3 = w2 + (size_t)KB * MS * 256;
+            float* bn = hs.bias.data() + (size_t)ni * hs.bias_floats;
+            for (int kb = 0; kb < KB; ++kb) {
+                const bool real = kb < (int)K.src.size();
+                hs.kb1tab[((size_t)ni * KB + kb) * 2] = real ? K.src[kb] : K.src[0];
+                hs.kb1tab[((size_t)ni * KB + kb) * 2 + 1] = real ? K.nk[kb] : 0;
+                if (!real) continue;
+                hs.mfma_per_tile += (int64_t)K.nk[kb] * (nf * MS + MO);
+                for (int ms = 0; ms < MS && hs.ig_has_lr; ++ms) hs.mfma_per_tile += hs.ig_nks[ms];
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int i = lane & 15, gg = lane >> 4;
+                    for (int r = 0; r < 4; ++r) {
+                        const int cs = K.pos[kb * 16 + 4 * r + gg];           // input position of this k-slot
+                        // W1: rows = slow features, k-slots = expanded input positions
+                        for (int fi = 0; fi < nf; ++fi)
+                            for (int ms = 0; ms < MS; ++ms) {
+                                const int fs = 16 * ms + q_of_row(i);
+                                if (fs < k && cs >= 0 && cs < used[fi])
+                                    w1[(((size_t)fi * KB + kb) * MS + ms) * 256 + lane * 4 + r] =
+                                        (float)nd.ig_sfa.W[(size_t)(foff[fi] + cs) * k + fs];
+                            }
+                        // W3: rows = output features k.., k-slots = residual positions
+                        for (int mo = 0; mo < MO; ++mo) {
+                            const int f = 16 * mo + q_of_row(i);
+                            if (f >= k && f < k + Q && cs >= 0)
+                                w3[((size_t)kb * MO + mo) * 256 + lane * 4 + r] = (float)nd.ig_pca.W[(size_t)cs * Q + (f - k)];
+                        }
+                        // W2: rows = residual positions of this block, k-slots = slow features of tile ms
+                        const int crow = K.pos[kb * 16 + q_of_row(i)];
+                        if (hs.ig_has_lr && crow >= 0)
+                            for (int ms = 0; ms < MS; ++ms) {
+                                const int fs = 16 * ms + 4 * r + gg;
+                                if (fs < k) w2[((size_t)kb * MS + ms) * 256 + lane * 4 + r] = (float)(-nd.ig_lr.W[(size_t)fs * d + crow]);
+                            }
+                    }
+                }
+                for (int gg = 0; gg < 4; ++gg)
+                    for (int r = 0; r < 4; ++r) {
+                        const int c = K.pos[kb * 16 + 4 * r + gg];
+                        if (c < 0) continue;
+                        double brv = 0;
+                        if (hs.ig_has_lr) {
+                            brv = -nd.ig_lr.b[c];
+                            for (int fs = 0; fs < k; ++fs) brv += nd.ig_lr.a[fs] * nd.ig_lr.W[(size_t)fs * d + c];
+                        }
+                        bn[MO * 16 + kb * 16 + gg * 4 + r] = (float)brv;
+                        bn[MO * 16 + KB * 16 + kb * 16 + gg * 4 + r] = (float)nd.ig_mean[c];
+                    }
+            }
+            for (int mo = 0; mo < MO; ++mo)
+                for (int gg = 0; gg < 4; ++gg)
+                    for (int r = 0; r < 4; ++r) {
+                        const int f = 16 * mo + 4 * r + gg;
+                        double v = 0;
+                        if (f < k) {
+                            v = nd.ig_sfa.b[f];
+                            for (int e = 0; e < nd.ig_sfa.in; ++e) v -= nd.ig_sfa.a[e] * nd.ig_sfa.W[(size_t)e * k + f];
+                        } else if (f < k + Q) {
+                            v = nd.ig_pca.b[f - k];
+                            for (int c = 0; c < d; ++c) v -= nd.ig_pca.a[c] * nd.ig_pca.W[(size_t)c * Q + (f - k)];
+                        }
+                        bn[mo * 16 + gg * 4 + r] = (float)v;
+                    }
+            for (int f = 0; f < nd.out_dim; ++f) {
+                cur_blk.push_back(ni * MO + f / 16);
+                cur_q.push_back(f % 16);
+            }
+        }
+        hs.nb_out = n * MO;
+        prev_blk.swap(cur_blk);
+        prev_q.swap(cur_q);
+        prev_nb = hs.nb_out;
+        max_nb_ = std::max(max_nb_, hs.nb_out);
+        padded_flops_ += hs.mfma_per_tile * 2048 / 16;
+        std::ostringstream os;
+        os << "fused iGSFA stage: " << n << " nodes, K-blocks " << KB << ", slow tiles " << MS << ", out tiles " << MO << ", "
+           << hs.mfma_per_tile << " MFMA/tile, " << hs.afrag.size() * 4 / 1024 << " KiB weights";
+        hs.name = os.str();
+    }
+
     // Layers 0 and 1 can share one kernel when a wave's two layer-0 node slots are exactly the two
     // children of one layer-1 node (see k_stage01p).
     bool can_fuse01() const {
         if (stages_.size() < 2) return false;
         const HostStage& a = stages_[0];
         const HostStage& b = stages_[1];
+        if (a.kind != 0 || b.kind != 0 || !a.from_x) return false;
         if (!(a.has_exp && a.mt1 == 1 && a.mt2 == 1 && a.kb1 == 1 && a.nf >= 1 && a.nf <= 2 && a.contig4 && a.vec_ok)) return false;
         if (a.max_chunk_nodes > 16 || a.max_chunk_pieces > 64) return false;
         for (auto& c : a.chunks)
@@ -1826,7 +2271,7 @@ std::unique_ptr<Executor> make_fused_executor(const TNode& root, std::string* wh
             return nullptr;
         }
         for (auto& n : st.nodes) {
-            bool same = n.has_exp == f0.has_exp && n.funcs.size() == f0.funcs.size();
+            bool same = n.has_exp == f0.has_exp && n.is_ig == f0.is_ig && n.funcs.size() == f0.funcs.size();
             for (size_t i = 0; same && i < n.funcs.size(); ++i)
                 same = n.funcs[i].kind == f0.funcs[i].kind && n.funcs[i].expo == f0.funcs[i].expo && n.funcs[i].sel == f0.funcs[i].sel;
             if (!same) {
@@ -1836,7 +2281,12 @@ std::unique_ptr<Executor> make_fused_executor(const TNode& root, std::string* wh
         }
     }
     if (why_not) why_not->clear();
-    return std::make_unique<FusedExecutor>(root, std::move(stages));
+    try {
+        return std::make_unique<FusedExecutor>(root, std::move(stages));
+    } catch (const Error& e) {      // a structure the fused kernels do not cover: generic plan instead
+        if (why_not) *why_not = e.what();
+        return nullptr;
+    }
 }
 
 }  // namespace hg

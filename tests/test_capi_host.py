@@ -50,7 +50,8 @@ def test_plans(native_lib, nets):
     assert Flow(helpers.overlapping_net()).host_plan()[0].plan_kind == _capi.HG_PLAN_FUSED
     assert Flow(helpers.linear_net()).host_plan()[0].plan_kind == _capi.HG_PLAN_FUSED
     inf, desc = Flow(nets("T5L-16", node_kind="igsfa")).host_plan()
-    assert inf.plan_kind == _capi.HG_PLAN_GENERIC and "iGSFA" in desc
+    assert inf.plan_kind == _capi.HG_PLAN_FUSED and "fused gather" in desc and "fused iGSFA stage" in desc
+    assert inf.padded_flops_per_row >= inf.flops_per_row > 0
     inf, desc = Flow(helpers.product_net()).host_plan()
     assert inf.plan_kind == _capi.HG_PLAN_GENERIC and "fused plan not used" in desc
     assert Flow(nets("T5L-16"), force_generic=True).host_plan()[0].plan_kind == _capi.HG_PLAN_GENERIC

@@ -77,6 +77,24 @@ def test_u11l_128_matches_oracle(native_lib, nets, force_generic):
     flow.close()
 
 
+def test_u11l_128_igsfa_matches_oracle(native_lib, nets):
+    """The 11-layer hierarchy with iGSFA nodes (HiGSFA proper) on the fused plan:
+    gather + 11 iGSFA stages, three chained GEMMs per node in registers."""
+    nodes = nets("U11L-128", node_kind="igsfa")
+    x = synth.make_subimages(200, 128, dtype=np.uint8)
+    ref = oracle.execute_flow(nodes, x)
+    flow = Flow(nodes)
+    assert flow.info().plan_kind == _capi.HG_PLAN_FUSED
+    y = flow.execute(x)
+    err = rel_err(y, ref)
+    print("U11L-128 iGSFA max|d|/max|ref| = %.3e" % err)
+    assert err <= TOL
+    gen = Flow(nodes, force_generic=True)
+    assert rel_err(gen.execute(x[:48]), ref[:48]) <= TOL
+    flow.close()
+    gen.close()
+
+
 def test_u11l_64_matches_oracle(native_lib, nets):
     """The shipped pipelines feed 64x64 sub-images (Pipelines/Pipeline_experimental.txt:2)."""
     nodes = nets("U11L-64")
