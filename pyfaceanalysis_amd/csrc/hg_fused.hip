@@ -1102,7 +1102,7 @@ __global__ void __launch_bounds__(512) k_stage01p(StageParams P, StageParams Q) 
 // gathers the four columns of its four k-steps for sub-image j.
 template <typename XT>
 __global__ void __launch_bounds__(256) k_im2frag(const XT* __restrict__ x, int64_t ldx, int64_t n_rows, int n_tiles, int nb,
-                                                 const int32_t* __restrict__ gcol, f32x4* __restrict__ out) {
+                                                 const int32_t* __restrict__ gcol, f32x4* __restrict__ out, int vec4) {
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
     const int64_t wid = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (wid >= (int64_t)n_tiles * nb) return;
@@ -1112,9 +1112,13 @@ __global__ void __launch_bounds__(256) k_im2frag(const XT* __restrict__ x, int64
     f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
     if (row < n_rows) {
         const XT* xr = x + row * ldx;
+        if (vec4 && c[0] >= 0 && c[3] == c[0] + 3) {     // four contiguous, 16-byte aligned columns
+            v = Vec4Load<XT>::ld(xr + c[0]);
+        } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (c[r] >= 0) v[r] = (float)xr[c[r]];
+            for (int r = 0; r < 4; ++r)
+                if (c[r] >= 0) v[r] = (float)xr[c[r]];
+        }
     }
     out[(size_t)wid * 64 + lane] = v;
 }
@@ -1134,12 +1138,15 @@ __global__ void __launch_bounds__(512, 2) k_igsfa(StageParams P) {
     constexpr int KBM = 8;   // K-blocks of a node input (<= 128 inputs)
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, nw = nthr >> 6, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int node = blockIdx.x % P.n_nodes, part = blockIdx.x / P.n_nodes;
-    float* sb = (float*)(smem + (size_t)P.node_blocks * 64);
-    int2* stab = (int2*)(sb + P.bias_floats);
+    // a workgroup owns a group of `nodes_per_group` consecutive nodes (their weights fit LDS together)
+    const int npg = P.nodes_per_group;
+    const int grp_id = blockIdx.x % P.n_chunks, part = blockIdx.x / P.n_chunks;
+    const int g0 = grp_id * npg, gn = min(npg, P.n_nodes - g0);
+    float* sb = (float*)(smem + (size_t)npg * P.node_blocks * 64);
+    int2* stab = (int2*)(sb + npg * P.bias_floats);
     {
-        const f32x4* src = P.afrag + (size_t)node * P.node_blocks * 64;
-        const int nvec = P.node_blocks * 64;
+        const f32x4* src = P.afrag + (size_t)g0 * P.node_blocks * 64;
+        const int nvec = gn * P.node_blocks * 64;
         int i = tid;
         for (; i + 3 * nthr < nvec; i += 4 * nthr) {
             f32x4 v0 = src[i], v1 = src[i + nthr], v2 = src[i + 2 * nthr], v3 = src[i + 3 * nthr];
@@ -1149,31 +1156,34 @@ __global__ void __launch_bounds__(512, 2) k_igsfa(StageParams P) {
             smem[i + 3 * nthr] = v3;
         }
         for (; i < nvec; i += nthr) smem[i] = src[i];
-        const float* bsrc = P.bias + (size_t)node * P.bias_floats;
-        for (int k = tid; k < P.bias_floats; k += nthr) sb[k] = bsrc[k];
-        const int2* tsrc = P.kb1tab + (size_t)node * P.kb1;
-        for (int k = tid; k < P.kb1; k += nthr) stab[k] = tsrc[k];
+        const float* bsrc = P.bias + (size_t)g0 * P.bias_floats;
+        for (int k = tid; k < gn * P.bias_floats; k += nthr) sb[k] = bsrc[k];
+        const int2* tsrc = P.kb1tab + (size_t)g0 * P.kb1;
+        for (int k = tid; k < gn * P.kb1; k += nthr) stab[k] = tsrc[k];
     }
     __syncthreads();
     const int kb1 = P.kb1, nf = P.nf;
-    const f32x4* w1 = smem + lane;                                  // [fi][kb][ms]
-    const f32x4* w2 = w1 + (size_t)nf * kb1 * MS * 64;              // [kb][ms]
-    const f32x4* w3 = w2 + (size_t)kb1 * MS * 64;                   // [kb][mo]
-    const float* by = sb;                                           // [MO][16]
-    const float* br = sb + MO * 16;                                 // [kb][16]
-    const float* mu = br + kb1 * 16;                                // [kb][16]
     for (int grp = part; grp < P.tile_groups; grp += P.tile_parts) {
         int tile[T];
 #pragma unroll
         for (int t = 0; t < T; ++t) tile[t] = (grp * nw + wave) * T + t;
         if (tile[0] >= P.n_tiles) break;
+      for (int ln = 0; ln < gn; ++ln) {
+        const int node = g0 + ln;
+        const f32x4* w1 = smem + (size_t)ln * P.node_blocks * 64 + lane;   // [fi][kb][ms]
+        const f32x4* w2 = w1 + (size_t)nf * kb1 * MS * 64;              // [kb][ms]
+        const f32x4* w3 = w2 + (size_t)kb1 * MS * 64;                   // [kb][mo]
+        const float* by = sb + ln * P.bias_floats;                      // [MO][16]
+        const float* br = by + MO * 16;                                 // [kb][16]
+        const float* mu = br + kb1 * 16;                                // [kb][16]
+        const int2* ktab = stab + ln * kb1;
         f32x4 x0[KBM][T];
         int nk1[KBM];
 #pragma unroll
         for (int kb = 0; kb < KBM; ++kb) {
             nk1[kb] = 0;
             if (kb < kb1) {
-                const int2 e = stab[kb];
+                const int2 e = ktab[kb];
                 const int sbk = __builtin_amdgcn_readfirstlane(e.x);
                 nk1[kb] = __builtin_amdgcn_readfirstlane(e.y);
                 const f32x4 m = *(const f32x4*)(mu + kb * 16 + g * 4);
@@ -1246,6 +1256,7 @@ __global__ void __launch_bounds__(512, 2) k_igsfa(StageParams P) {
 #pragma unroll
             for (int t = 0; t < T; ++t)
                 if (tile[t] < P.n_tiles) P.out[((size_t)tile[t] * P.nb_out + (size_t)node * MO + mo) * 64 + lane] = y[mo][t];
+      }
     }
 }
 
@@ -1695,12 +1706,14 @@ public:
             if (s.kind == 1) {        // row-major input -> fragment order
                 const int64_t waves = (int64_t)n_tiles * s.nb_out;
                 const unsigned grid = (unsigned)((waves + 3) / 4);
+                const size_t esz0 = dtype_size(x_dtype), al0 = x_dtype == HG_U8 ? 4 : 16;
+                const int v4 = (s.vec_ok && ldx % 4 == 0 && ((uintptr_t)x % al0) == 0 && (ldx * esz0) % al0 == 0) ? 1 : 0;
                 if (x_dtype == HG_U8)
-                    hipLaunchKernelGGL(k_im2frag<uint8_t>, grid, 256, 0, st, (const uint8_t*)x, ldx, n, n_tiles, s.nb_out, (const int32_t*)s.d_gcol.p, nxt);
+                    hipLaunchKernelGGL(k_im2frag<uint8_t>, grid, 256, 0, st, (const uint8_t*)x, ldx, n, n_tiles, s.nb_out, (const int32_t*)s.d_gcol.p, nxt, v4);
                 else if (x_dtype == HG_F32)
-                    hipLaunchKernelGGL(k_im2frag<float>, grid, 256, 0, st, (const float*)x, ldx, n, n_tiles, s.nb_out, (const int32_t*)s.d_gcol.p, nxt);
+                    hipLaunchKernelGGL(k_im2frag<float>, grid, 256, 0, st, (const float*)x, ldx, n, n_tiles, s.nb_out, (const int32_t*)s.d_gcol.p, nxt, v4);
                 else
-                    hipLaunchKernelGGL(k_im2frag<double>, grid, 256, 0, st, (const double*)x, ldx, n, n_tiles, s.nb_out, (const int32_t*)s.d_gcol.p, nxt);
+                    hipLaunchKernelGGL(k_im2frag<double>, grid, 256, 0, st, (const double*)x, ldx, n, n_tiles, s.nb_out, (const int32_t*)s.d_gcol.p, nxt, v4);
                 std::swap(cur, nxt);
                 if (ev) HG_HIP(hipEventRecord(ev[e++], st));
                 continue;
@@ -1713,11 +1726,14 @@ public:
                 P.nk2p[0] = 0;
                 for (int ms = 0; ms < s.mt1; ++ms) P.nk2p[0] |= (uint32_t)s.ig_nks[ms] << (4 * ms);
                 P.tile_groups = (n_tiles + nw * T - 1) / (nw * T);
-                P.tile_parts = std::max(1, std::min(P.tile_groups, 512 / std::max(1, s.n_nodes)));
-                const size_t lds_bytes = (size_t)s.node_blocks * 1024 + (size_t)s.bias_floats * 4 + (size_t)s.kb1 * 8;
+                const int npg = 1;   // one node per workgroup measured fastest (236/180 us vs 246-288/220-269 us with 32-96 KiB groups on the 11-layer net)
+                P.nodes_per_group = npg;
+                P.n_chunks = (s.n_nodes + npg - 1) / npg;
+                P.tile_parts = std::max(1, std::min(P.tile_groups, 512 / std::max(1, P.n_chunks)));
+                const size_t lds_bytes = (size_t)npg * (s.node_blocks * 1024 + (size_t)s.bias_floats * 4 + (size_t)s.kb1 * 8);
                 StageFn fn = pick_igsfa(s.mt1, s.mt2, T);
                 set_lds_limit(fn, lds_bytes);
-                hipLaunchKernelGGL(fn, (unsigned)(s.n_nodes * P.tile_parts), nw * 64, lds_bytes, st, P);
+                hipLaunchKernelGGL(fn, (unsigned)(P.n_chunks * P.tile_parts), nw * 64, lds_bytes, st, P);
                 std::swap(cur, nxt);
                 if (ev) HG_HIP(hipEventRecord(ev[e++], st));
                 continue;
@@ -2061,6 +2077,9 @@ private:
                 prev_q[nd.in_off + c] = q;
             }
         }
+        hs.vec_ok = tr;
+        for (size_t e4 = 0; e4 < hs.gcol.size() && hs.vec_ok; e4 += 4)
+            if (hs.gcol[e4] >= 0 && hs.gcol[e4 + 3] == hs.gcol[e4] + 3 && hs.gcol[e4] % 4) hs.vec_ok = false;
         for (int i = 0; i < in_w; ++i) st.conn[i] = i;
         prev_nb = hs.nb_out;
         max_nb_ = std::max(max_nb_, hs.nb_out);
