@@ -305,6 +305,12 @@ struct StageParams {
     unsigned long long* stamps;   // diagnostic build only (HIGSFA_STAMP): per-wave cycle stamps
 };
 
+__device__ __forceinline__ unsigned long long stamp_now() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+
 __device__ __forceinline__ float pow_abs(float v, float p) {
     // |v|^p = exp2(p * log2|v|); v = 0 -> log2 = -inf -> exp2 = 0 exactly
     return __builtin_amdgcn_exp2f(p * __builtin_amdgcn_logf(__builtin_fabsf(v)));
@@ -403,12 +409,6 @@ __device__ __forceinline__ void node_tail(const StageParams& P, WP wA2, BP b2, i
 #pragma unroll
         for (int t = 0; t < T; ++t)
             if (tile[t] < P.n_tiles) P.out[((size_t)tile[t] * P.nb_out + out_blk + mt) * 64 + lane] = y[mt][t];
-}
-
-__device__ __forceinline__ unsigned long long stamp_now() {
-    unsigned long long t;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-    return t;
 }
 
 // Stages > 0.  A workgroup of NW waves owns NW*T batch tiles and walks a range of nodes; the
@@ -908,7 +908,7 @@ __global__ void __launch_bounds__(512) k_stage0p(StageParams P) {
 // layer-0 activation (64 KiB per sub-image written and read back) never exists in memory.
 // Requirements checked on the host: layer 0 as for k_stage0p; layer-1 node n reads exactly the
 // blocks of layer-0 nodes 2n and 2n+1; both layer-1 affines have <= 32 outputs; same <= 2 functions.
-template <typename XT>
+template <typename XT, bool STAMP = false>
 __global__ void __launch_bounds__(512) k_stage01p(StageParams P, StageParams Q) {
     extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
     float* lds = (float*)smem;
@@ -921,19 +921,21 @@ __global__ void __launch_bounds__(512) k_stage01p(StageParams P, StageParams Q) 
     const int stride = P.lds_stride;
     const int n_groups = (P.n_tiles + T - 1) / T;
     const int pps = ck.n_pieces, total = T * 16 * pps;
-    int p_col[NB], p_dst[NB];
+    const XT* p_src[NB];   // address of the piece in tile group 0; a group advances every piece by T*16 rows
+    int p_dst[NB];
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
         const int idx = k * nthr + tid;
-        p_col[k] = 0;
+        p_src[k] = x;
         p_dst[k] = -1;
         if (idx < total) {
             const int sj = idx / pps, pc = idx - sj * pps;
             const int2 pcol = P.piece_col[ck.piece_begin + pc];
-            p_col[k] = pcol.x;
+            p_src[k] = x + (int64_t)sj * P.ldx + pcol.x;
             p_dst[k] = (sj << 24) | (sj * stride + pcol.y);
         }
     }
+    const int64_t grp_step = (int64_t)(T * 16) * P.ldx;
     // layer-0 weights of the two slots
     int w_off[NPW];
     f32x4 w_mu[NPW], w_a1[NPW], w_a2[NPW][2], w_b1[NPW], w_b2[NPW];
@@ -975,19 +977,18 @@ __global__ void __launch_bounds__(512) k_stage01p(StageParams P, StageParams Q) 
             q_b2[mt] = *(const f32x4*)(bq + 32 + mt * 16);
         }
     }
-    const int nk1 = P.nk_last;
-    const int nk2a = P.nk2p[0] & 15, nk2b = (P.nk2p[0] >> 4) & 15;
     const int fk0 = P.funcp & 15, fk1 = (P.funcp >> 4) & 15;
     const float ex0 = P.expo[0], ex1 = P.expo[1];
     const int qfk0 = Q.funcp & 15, qfk1 = (Q.funcp >> 4) & 15;
     const float qex0 = Q.expo[0], qex1 = Q.expo[1];
 
     auto fetch = [&](int grp, f32x4 (&v)[NB]) {
+        const int64_t goff = (int64_t)grp * grp_step;            // wave-uniform
+        const int64_t rows_left = P.n_rows - (int64_t)grp * (T * 16);
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
-            const int64_t row = (int64_t)grp * (T * 16) + (p_dst[k] >> 24);
-            if (p_dst[k] >= 0 && row < P.n_rows)
-                v[k] = Vec4Load<XT>::ld(x + row * P.ldx + p_col[k]);
+            if (p_dst[k] >= 0 && (p_dst[k] >> 24) < rows_left)
+                v[k] = Vec4Load<XT>::ld(p_src[k] + goff);
             else
                 v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -999,7 +1000,14 @@ __global__ void __launch_bounds__(512) k_stage01p(StageParams P, StageParams Q) 
     const int buf_words = T * 16 * stride;
     float* lds0 = lds;
     int flip = 0;
+    unsigned long long t_w = 0, t_f = 0, t_l0 = 0, t_l1 = 0, t_all0 = 0, rt0 = 0, ts = 0;
+    int n_it = 0;
+    if (STAMP) {
+        t_all0 = stamp_now();
+        rt0 = __builtin_amdgcn_s_memrealtime();
+    }
     for (int grp = part; grp < n_groups; grp += P.tile_parts) {
+        if (STAMP) ts = stamp_now();
         lds = lds0 + flip * buf_words;
         flip ^= 1;
 #pragma unroll
@@ -1007,7 +1015,9 @@ __global__ void __launch_bounds__(512) k_stage01p(StageParams P, StageParams Q) 
             if (p_dst[k] >= 0) *(f32x4*)(lds + (p_dst[k] & 0xffffff)) = v[k];
         if (tid < T * 16) lds[tid * stride + stride - 1] = 0.f;
         __syncthreads();
+        if (STAMP) { unsigned long long t = stamp_now(); t_w += t - ts; ts = t; }
         if (grp + P.tile_parts < n_groups) fetch(grp + P.tile_parts, v);
+        if (STAMP) { unsigned long long t = stamp_now(); t_f += t - ts; ts = t; }
         if (w_ok) {
             int tile[T];
 #pragma unroll
@@ -1025,33 +1035,28 @@ __global__ void __launch_bounds__(512) k_stage01p(StageParams P, StageParams Q) 
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (r < nk1) {
 #pragma unroll
-                        for (int t = 0; t < T; ++t) z[t] = MFMA16(w_a1[sl][r], bf[t][r], z[t]);
-                    }
+                    for (int t = 0; t < T; ++t) z[t] = MFMA16(w_a1[sl][r], bf[t][r], z[t]);
                 {
                     f32x4 e[T];
 #pragma unroll
                     for (int t = 0; t < T; ++t) e[t] = apply_func(fk0, ex0, z[t]);
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (r < nk2a) {
 #pragma unroll
-                            for (int t = 0; t < T; ++t) y0[sl][t] = MFMA16(w_a2[sl][0][r], e[t][r], y0[sl][t]);
-                        }
+                        for (int t = 0; t < T; ++t) y0[sl][t] = MFMA16(w_a2[sl][0][r], e[t][r], y0[sl][t]);
                 }
-                if (P.nf > 1) {
+                {
                     f32x4 e[T];
 #pragma unroll
                     for (int t = 0; t < T; ++t) e[t] = apply_func(fk1, ex1, z[t]);
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (r < nk2b) {
 #pragma unroll
-                            for (int t = 0; t < T; ++t) y0[sl][t] = MFMA16(w_a2[sl][1][r], e[t][r], y0[sl][t]);
-                        }
+                        for (int t = 0; t < T; ++t) y0[sl][t] = MFMA16(w_a2[sl][1][r], e[t][r], y0[sl][t]);
                 }
             }
+            if (STAMP) { unsigned long long t = stamp_now(); t_l0 += t - ts; ts = t; }
             // ---- layer 1: K-blocks of the first affine are the children's accumulators
             f32x4 z1[2][T], y1[2][T];
 #pragma unroll
@@ -1070,30 +1075,46 @@ __global__ void __launch_bounds__(512) k_stage01p(StageParams P, StageParams Q) 
 #pragma unroll
                         for (int t = 0; t < T; ++t) z1[mt][t] = MFMA16(q_a1[kb][mt][r], y0[kb][t][r], z1[mt][t]);
 #pragma unroll
-            for (int m1 = 0; m1 < 2; ++m1) {
+            for (int fi = 0; fi < 2; ++fi) {        // z tile 0: full, branch-free
+                f32x4 e[T];
 #pragma unroll
-                for (int fi = 0; fi < 2; ++fi) {
-                    const int nk = fi < Q.nf ? (int)((Q.nk2p[m1] >> (4 * fi)) & 15) : 0;
-                    if (nk == 0) continue;
-                    f32x4 e[T];
+                for (int t = 0; t < T; ++t) e[t] = apply_func(fi == 0 ? qfk0 : qfk1, fi == 0 ? qex0 : qex1, z1[0][t]);
 #pragma unroll
-                    for (int t = 0; t < T; ++t) e[t] = apply_func(fi == 0 ? qfk0 : qfk1, fi == 0 ? qex0 : qex1, z1[m1][t]);
+                for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (r < nk) {
+                    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                            for (int mt = 0; mt < 2; ++mt)
+                        for (int t = 0; t < T; ++t) y1[mt][t] = MFMA16(q_a2[0][fi][mt][r], e[t][r], y1[mt][t]);
+            }
 #pragma unroll
-                                for (int t = 0; t < T; ++t) y1[mt][t] = MFMA16(q_a2[m1][fi][mt][r], e[t][r], y1[mt][t]);
-                        }
-                }
+            for (int fi = 0; fi < 2; ++fi) {        // z tile 1: partial (runtime k-step count)
+                const int nk = (int)((Q.nk2p[1] >> (4 * fi)) & 15);
+                f32x4 e[T];
+#pragma unroll
+                for (int t = 0; t < T; ++t) e[t] = apply_func(fi == 0 ? qfk0 : qfk1, fi == 0 ? qex0 : qex1, z1[1][t]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (r < nk) {
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                            for (int t = 0; t < T; ++t) y1[mt][t] = MFMA16(q_a2[1][fi][mt][r], e[t][r], y1[mt][t]);
+                    }
             }
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int t = 0; t < T; ++t)
                     if (tile[t] < P.n_tiles) Q.out[((size_t)tile[t] * Q.nb_out + (size_t)n1 * Q.mto + mt) * 64 + lane] = y1[mt][t];
+            if (STAMP) { unsigned long long t = stamp_now(); t_l1 += t - ts; ts = t; ++n_it; }
         }
+    }
+    if (STAMP && lane == 0 && P.stamps) {
+        unsigned long long* o = P.stamps + ((size_t)blockIdx.x * 8 + wave) * 8;
+        o[0] = t_w; o[1] = t_f; o[2] = t_l0; o[3] = t_l1;
+        o[4] = stamp_now() - t_all0;
+        o[5] = __builtin_amdgcn_s_memrealtime() - rt0;
+        o[6] = (unsigned long long)n_it;
     }
 }
 
@@ -1779,7 +1800,27 @@ public:
                         }
                     }
                     P.tile_parts = std::max(1, std::min(groups2, 256 * occ / std::max(1, P.n_chunks)));
+                    const char* stamp_env = getenv("HIGSFA_STAMP");
+                    if (stamp_env && atoi(stamp_env) == 0 && x_dtype == HG_F32) {
+                        fn = (StageFn2)k_stage01p<float, true>;
+                        stamp_blocks_ = P.n_chunks * P.tile_parts;
+                        stamp_buf_.alloc((size_t)stamp_blocks_ * 8 * 8 * 8);
+                        HG_HIP(hipMemsetAsync(stamp_buf_.p, 0, stamp_buf_.bytes, st));
+                        P.stamps = (unsigned long long*)stamp_buf_.p;
+                    }
                     hipLaunchKernelGGL(fn, (unsigned)(P.n_chunks * P.tile_parts), thr01, lds2, st, P, Q);
+                    if (P.stamps) {
+                        HG_HIP(hipStreamSynchronize(st));
+                        std::vector<unsigned long long> h((size_t)stamp_blocks_ * 8 * 8);
+                        HG_HIP(hipMemcpy(h.data(), stamp_buf_.p, h.size() * 8, hipMemcpyDeviceToHost));
+                        double a[7] = {0, 0, 0, 0, 0, 0, 0}, nwv = 0;
+                        for (size_t i = 0; i < h.size(); i += 8)
+                            if (h[i + 4]) { for (int k = 0; k < 7; ++k) a[k] += h[i + k]; nwv += 1; }
+                        fprintf(stderr, "[stamp stage 0+1] waves %.0f clock %.0f MHz lifetime %.1f us, iterations %.1f; cycles per iteration: "
+                                        "lds-write+barrier %.0f, fetch issue %.0f, layer0 %.0f, layer1+store %.0f (sum %.0f)\n",
+                                nwv, a[4] / a[5] * 100.0, a[5] / nwv / 100.0, a[6] / nwv, a[0] / a[6], a[1] / a[6], a[2] / a[6], a[3] / a[6],
+                                (a[0] + a[1] + a[2] + a[3]) / a[6]);
+                    }
                     if (ev) {
                         HG_HIP(hipEventRecord(ev[e++], st));   // stage 0 (carries the fused time)
                         HG_HIP(hipEventRecord(ev[e++], st));   // stage 1 (fused: no launch of its own)
@@ -2246,11 +2287,12 @@ private:
         const HostStage& a = stages_[0];
         const HostStage& b = stages_[1];
         if (a.kind != 0 || b.kind != 0 || !a.from_x) return false;
-        if (!(a.has_exp && a.mt1 == 1 && a.mt2 == 1 && a.kb1 == 1 && a.nf >= 1 && a.nf <= 2 && a.contig4 && a.vec_ok)) return false;
+        if (!(a.has_exp && a.mt1 == 1 && a.mt2 == 1 && a.kb1 == 1 && a.nf == 2 && a.contig4 && a.vec_ok)) return false;
+        if (a.nk_last != 4 || a.nk2[0][0] != 4 || a.nk2[0][1] != 4) return false;   // the kernel runs all four k-steps unconditionally
         if (a.max_chunk_nodes > 16 || a.max_chunk_pieces > 64) return false;
         for (auto& c : a.chunks)
             if ((c.node_begin & 1) || (c.node_count & 1)) return false;
-        if (!(b.has_exp && b.mt1 == 2 && b.mt2 == 2 && b.kb1 == 2 && b.nf >= 1 && b.nf <= 2)) return false;
+        if (!(b.has_exp && b.mt1 == 2 && b.mt2 == 2 && b.kb1 == 2 && b.nf == 2 && b.nk2[0][0] == 4 && b.nk2[0][1] == 4)) return false;
         if (b.n_nodes * 2 != a.n_nodes) return false;
         for (int n = 0; n < b.n_nodes; ++n)
             if (b.kb1tab[(size_t)n * 4] != 2 * n || b.kb1tab[(size_t)n * 4 + 2] != 2 * n + 1) return false;
