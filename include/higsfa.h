@@ -133,6 +133,24 @@ int hg_gauss_regression_device(hg_gauss* g, const void* x_dev, int x_dtype, int6
 int hg_gauss_regression(hg_gauss* g, const void* x, int x_dtype, int64_t n, int64_t ldx,
                         double* out_reg, double* out_std);
 
+/* --- On-device sub-image extraction ---------------------------------------
+ * The producer of the hot call's input: load_network_subimages -> extract_subimages_rotate
+ * (face_analysis.py:775-800; FaceDetectUpdated.py:686), which crops every window with PIL's
+ * Image.transform((w, h), EXTENT, (x0, y0, x1, y1), NEAREST).  Same index rule, bit for bit
+ * (tested against PIL); rotation angles other than 0 are not covered.
+ * frame: (frame_h, frame_w) pixels, HG_U8 or HG_F32, row stride ld elements.  boxes: n x 4 doubles
+ * (x0, y0, x1, y1) in frame coordinates.  out: n rows of out_w*out_h elements (row-major pixels,
+ * the layout flow.execute expects), row stride ldo elements, dtype U8 / F32 / F64. */
+typedef struct hg_patcher hg_patcher;
+int hg_patcher_create(int device, hg_patcher** out);
+void hg_patcher_free(hg_patcher* p);
+int hg_patcher_extract_device(hg_patcher* p, const void* frame_dev, int frame_dtype, int frame_h, int frame_w,
+                              int64_t ld, const double* boxes_dev, int64_t n, int out_w, int out_h,
+                              void* out_dev, int out_dtype, int64_t ldo, void* stream);
+int hg_patcher_extract(hg_patcher* p, const void* frame, int frame_dtype, int frame_h, int frame_w, int64_t ld,
+                       const double* boxes, int64_t n, int out_w, int out_h, void* out, int out_dtype,
+                       int64_t ldo);
+
 #ifdef __cplusplus
 }
 #endif

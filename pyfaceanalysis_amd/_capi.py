@@ -58,6 +58,10 @@ def lib():
         "hg_gauss_free": (None, [vp]),
         "hg_gauss_regression_device": (C.c_int, [vp, vp, i32, i64, i64, vp, vp, vp]),
         "hg_gauss_regression": (C.c_int, [vp, vp, i32, i64, i64, vp, vp]),
+        "hg_patcher_create": (C.c_int, [i32, C.POINTER(vp)]),
+        "hg_patcher_free": (None, [vp]),
+        "hg_patcher_extract_device": (C.c_int, [vp, vp, i32, i32, i32, i64, vp, i64, i32, i32, vp, i32, i64, vp]),
+        "hg_patcher_extract": (C.c_int, [vp, vp, i32, i32, i32, i64, vp, i64, i32, i32, vp, i32, i64]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(L, name)
@@ -72,7 +76,8 @@ EXPORTED_SYMBOLS = (
     "hg_flow_describe", "hg_flow_to_device", "hg_flow_reserve", "hg_flow_execute",
     "hg_flow_execute_device", "hg_flow_set_profiling", "hg_flow_stage_times", "hg_flow_stage_name",
     "hg_flow_reset_profile", "hg_gauss_create", "hg_gauss_free", "hg_gauss_regression_device",
-    "hg_gauss_regression",
+    "hg_gauss_regression", "hg_patcher_create", "hg_patcher_free", "hg_patcher_extract_device",
+    "hg_patcher_extract",
 )
 
 _EXC = {HG_ERR_ARG: ValueError, HG_ERR_FORMAT: ValueError, HG_ERR_DIM: ValueError,
