@@ -151,6 +151,19 @@ int hg_patcher_extract(hg_patcher* p, const void* frame, int frame_dtype, int fr
                        const double* boxes, int64_t n, int out_w, int out_h, void* out, int out_dtype,
                        int64_t ldo);
 
+/* --- SFA training step for one layer of nodes (BASELINE.json configs[4]) -----
+ * Not on the reference's path (it never trains, face_analysis.py:451-479); restates
+ * mdp.nodes.SFANode train/stop_training per node k over input columns conn[k*d .. (k+1)*d):
+ * mean, B = Cov(x), A = Cov(x[t+1]-x[t]) accumulated in fp64 by a HIP kernel, then
+ * A w = lambda B w by rocSOLVER dsygvd (eigenvalues ascending, w' B w = 1).
+ * x: (n, ldx) matrix in time order, a device pointer or (x_on_host != 0) a host pointer that is
+ * copied to the device first.  Host outputs: evals (n_nodes, d), evecs
+ * (n_nodes, d, d) column-major per node (column i = eigenvector i), mean (n_nodes, d);
+ * timings_ms[2] (optional): statistics kernels, solve. */
+int hg_sfa_train_layer(const void* x, int x_on_host, int x_dtype, int64_t n, int64_t ldx, const int32_t* conn_host,
+                       int32_t n_nodes, int32_t d, int device, double* evals_host, double* evecs_host,
+                       double* mean_host, double* timings_ms);
+
 #ifdef __cplusplus
 }
 #endif

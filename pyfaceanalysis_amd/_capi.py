@@ -28,7 +28,12 @@ class NativeLibraryMissing(ImportError):
 
 
 def lib():
-    """Load libhigsfa.so (built by ``python -m pyfaceanalysis_amd.build``)."""
+    """Load libhigsfa.so (built by ``python -m pyfaceanalysis_amd.build``).
+
+    Load order with PyTorch: import torch BEFORE the first call of this function when both are used in
+    one process.  The torch wheel bundles its own ROCm runtime (torch/lib/libamdhip64.so, librocblas.so,
+    librocsolver.so); loaded first, it is the one runtime everything binds to.  The other way round the
+    system runtime owns the GPU and torch then reports "No HIP GPUs are available"."""
     global _lib
     if _lib is not None:
         return _lib
@@ -62,6 +67,7 @@ def lib():
         "hg_patcher_free": (None, [vp]),
         "hg_patcher_extract_device": (C.c_int, [vp, vp, i32, i32, i32, i64, vp, i64, i32, i32, vp, i32, i64, vp]),
         "hg_patcher_extract": (C.c_int, [vp, vp, i32, i32, i32, i64, vp, i64, i32, i32, vp, i32, i64]),
+        "hg_sfa_train_layer": (C.c_int, [vp, i32, i32, i64, i64, vp, C.c_int32, C.c_int32, i32, vp, vp, vp, vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(L, name)
@@ -77,7 +83,7 @@ EXPORTED_SYMBOLS = (
     "hg_flow_execute_device", "hg_flow_set_profiling", "hg_flow_stage_times", "hg_flow_stage_name",
     "hg_flow_reset_profile", "hg_gauss_create", "hg_gauss_free", "hg_gauss_regression_device",
     "hg_gauss_regression", "hg_patcher_create", "hg_patcher_free", "hg_patcher_extract_device",
-    "hg_patcher_extract",
+    "hg_patcher_extract", "hg_sfa_train_layer",
 )
 
 _EXC = {HG_ERR_ARG: ValueError, HG_ERR_FORMAT: ValueError, HG_ERR_DIM: ValueError,

@@ -1490,6 +1490,8 @@ public:
             }
             hs.node_blocks = hs.kb1 * hs.mt1 + (hs.has_exp ? hs.mt1 * hs.nf * hs.mt2 : 0);
             hs.bias_floats = (hs.mt1 + (hs.has_exp ? hs.mt2 : 0)) * 16;
+            if (si > 0 && (size_t)hs.node_blocks * 1024 + (size_t)hs.bias_floats * 4 + (size_t)hs.kb1 * 8 > 150 * 1024)
+                fail(HG_ERR_FORMAT, "fused: one node needs %d KiB of weight fragments, more than a workgroup's LDS", hs.node_blocks);
             hs.afrag.assign((size_t)n * hs.node_blocks * 256, 0.f);
             hs.bias.assign((size_t)n * hs.bias_floats, 0.f);
             if (si > 0) hs.kb1tab.assign((size_t)n * hs.kb1 * 2, 0);
@@ -2180,6 +2182,8 @@ private:
         for (int ms = 0; ms < MS; ++ms) hs.ig_nks[ms] = (std::min(16, k_max - 16 * ms) + 3) / 4;
         hs.node_blocks = nf * KB * MS + KB * MS + KB * MO;
         hs.bias_floats = MO * 16 + 2 * KB * 16;
+        if ((size_t)hs.node_blocks * 1024 + (size_t)hs.bias_floats * 4 + (size_t)KB * 8 > 150 * 1024)
+            fail(HG_ERR_FORMAT, "fused: one iGSFA node needs %d KiB of weight fragments, more than a workgroup's LDS", hs.node_blocks);
         hs.afrag.assign((size_t)n * hs.node_blocks * 256, 0.f);
         hs.bias.assign((size_t)n * hs.bias_floats, 0.f);
         hs.kb1tab.assign((size_t)n * KB * 2, 0);

@@ -58,3 +58,14 @@ def product_net(seed=0):
         l0.append(N.FlowNode([rand_pca(rng, 16, 5), ex, N.CutoffNode(ex.output_dim, -3.0, 3.0),
                               rand_sfa(rng, ex.output_dim, 8), N.HeadNode(8, 6)]))
     return [sb0, N.Layer(l0), N.IdentityNode(24), rand_pca(rng, 24, 10)]
+
+
+def wide_merge_net(seed=0):
+    """A layer whose nodes merge 40 children of 13 features each (520 inputs -> 40 K-blocks x 4 tiles of
+    weights = 160+ KiB per node): beyond what a workgroup's LDS holds, so the loader must pick the generic plan."""
+    rng = np.random.default_rng(seed)
+    l0 = N.Layer([N.FlowNode([rand_pca(rng, 4, 13), N.GeneralExpansionNode([N.identity], 13), rand_sfa(rng, 13, 13)])
+                  for _ in range(40)])
+    ex = N.GeneralExpansionNode([N.identity, N.unsigned_08expo], 50)
+    l1 = N.Layer([N.FlowNode([rand_pca(rng, 520, 50), ex, rand_sfa(rng, 100, 40)])])
+    return [l0, l1]

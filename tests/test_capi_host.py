@@ -55,6 +55,8 @@ def test_plans(native_lib, nets):
     inf, desc = Flow(helpers.product_net()).host_plan()
     assert inf.plan_kind == _capi.HG_PLAN_GENERIC and "fused plan not used" in desc
     assert Flow(nets("T5L-16"), force_generic=True).host_plan()[0].plan_kind == _capi.HG_PLAN_GENERIC
+    inf, desc = Flow(helpers.wide_merge_net()).host_plan()      # too much weight per node for LDS -> generic, with a reason
+    assert inf.plan_kind == _capi.HG_PLAN_GENERIC and "LDS" in desc
 
 
 def test_u11l_128_plan(native_lib, nets):

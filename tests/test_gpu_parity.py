@@ -50,7 +50,7 @@ def test_golden_fixtures(native_lib, path, force_generic):
 
 
 @pytest.mark.parametrize("force_generic", [True, False])
-@pytest.mark.parametrize("maker", [helpers.overlapping_net, helpers.linear_net, helpers.product_net])
+@pytest.mark.parametrize("maker", [helpers.overlapping_net, helpers.linear_net, helpers.product_net, helpers.wide_merge_net])
 def test_awkward_structures(native_lib, maker, force_generic):
     """Overlapping fields, irregular switchboards, uneven node widths, sel_exp, clone layers, folded
     affines, product expansions / Head / Cutoff (generic plan)."""
