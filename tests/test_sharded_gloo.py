@@ -52,9 +52,13 @@ def test_shard_bounds():
 def test_world_size_2_gloo(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER.format(root=ROOT))
+    import socket
+    with socket.socket() as sk:                      # a free port: fixed ports collide with earlier runs in TIME_WAIT
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-           "--master-addr", "127.0.0.1", "--master-port", "29531", str(script)]
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     out = r.stdout.decode(errors="replace")
     assert r.returncode == 0, out[-3000:]
