@@ -12,7 +12,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhigsfa.so")
-SOURCES = ["hg_tree.cpp", "hg_capi.cpp", "hg_generic.hip", "hg_fused.hip", "hg_gauss.hip", "hg_extract.hip", "hg_train.hip"]
+SOURCES = ["hg_tree.cpp", "hg_capi.cpp", "hg_generic.hip", "hg_fused.hip", "hg_fused_front.hip", "hg_fused_igsfa.hip",
+           "hg_gauss.hip", "hg_extract.hip", "hg_train.hip"]
 HEADERS = ["hg_common.hpp", os.path.join("..", "..", "include", "higsfa.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-unused-result"]

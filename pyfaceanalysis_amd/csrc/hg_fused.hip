@@ -28,16 +28,13 @@
 #include <sstream>
 #include <tuple>
 
-#include "hg_common.hpp"
+#include "hg_fused_dev.hpp"
 
 namespace hg {
 
 namespace {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int kMaxMT = 4;            // up to 64 outputs per affine in the fused plan
+using namespace fused;
 constexpr int kStage0MaxCols = 1022;  // columns of one sub-image staged in LDS per chunk
 
 // ---- host-side normal form ---------------------------------------------------------------------
@@ -264,151 +261,6 @@ bool build_stages(const TNode& root, std::vector<FStage>& stages, std::string& w
     if (have_pending) { why = "flow ends in a switchboard"; return false; }
     if (stages.empty()) { why = "no layer in the flow"; return false; }
     return true;
-}
-
-// ---- device side -------------------------------------------------------------------------------
-// Every stage is padded to a UNIFORM node structure (same K-block count, tile counts and
-// expansion list for all its nodes; missing pieces are zero weights), so all weight / bias
-// addresses are arithmetic on the node index and the only per-node table is the list of source
-// blocks of GEMM 1.
-constexpr int kMaxFuncs = 4;
-
-struct DChunk {   // stage 0: a group of consecutive nodes whose input columns share one LDS tile
-    int32_t node_begin, node_count, run_begin, run_count, n_cols, piece_begin, n_pieces, pad1;
-};
-struct DRun {
-    int32_t start, len, lds_off, pad;
-};
-
-struct StageParams {
-    const f32x4* afrag;   // [node][ A1: kb1 x MT1 | A2: MT1 x nf x MT2 ] blocks of 64 x f32x4
-    const float* bias;    // [node][ (MT1 + MT2) x 16 ]
-    const int2* kb1tab;   // [node][kb1] {source block, k-steps}           (stages > 0)
-    const f32x4* in;      // input activation, fragment order               (stages > 0)
-    f32x4* out;
-    int32_t n_nodes, kb1, nf, has_exp;
-    int32_t node_blocks, bias_floats, n_tiles, nb_in, nb_out, mto;
-    int32_t nodes_per_group, nodes_per_wg, n_chunks, tile_groups, tile_parts;
-    uint32_t nk2p[kMaxMT];     // per z tile: 4 bits of k-steps per expansion function
-    uint32_t funcp;            // 4 bits of ExpKind per expansion function
-    float expo[kMaxFuncs];
-    // stage 0
-    const DChunk* chunks;
-    const DRun* runs;
-    const int2* piece_col;     // per chunk piece (4 columns) -> {first source column, LDS word offset}
-    const int32_t* koff;       // [node*kb1 + kb][g][r] LDS word offsets
-    const float* kmean;        // same shape: means subtracted by the loader
-    const void* x;
-    int64_t ldx, n_rows;
-    int32_t lds_stride, nk_last, vec4, contig4;
-    int32_t ig_has_lr;
-    unsigned long long* stamps;   // diagnostic build only (HIGSFA_STAMP): per-wave cycle stamps
-};
-
-__device__ __forceinline__ unsigned long long stamp_now() {
-    unsigned long long t;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-    return t;
-}
-
-__device__ __forceinline__ float pow_abs(float v, float p) {
-    // |v|^p = exp2(p * log2|v|); v = 0 -> log2 = -inf -> exp2 = 0 exactly
-    return __builtin_amdgcn_exp2f(p * __builtin_amdgcn_logf(__builtin_fabsf(v)));
-}
-
-__device__ __forceinline__ f32x4 apply_func(int func, float expo, f32x4 z) {
-    f32x4 e;
-    if (func == (int)E_IDENTITY) {
-        e = z;
-    } else if (func == (int)E_ABS_POW) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) e[r] = pow_abs(z[r], expo);
-    } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) e[r] = __builtin_copysignf(pow_abs(z[r], expo), z[r]);
-    }
-    return e;
-}
-
-#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
-
-// One K-block: acc[mt][t] += A[mt] (16 x 16, four k-steps) * B[t].  `wp` points at the block's first
-// A fragment (+lane); fragments of consecutive m-tiles are 64 f32x4 apart.  With T >= 2 the A
-// fragment is read one m-tile at a time (4 live registers instead of 4*MT): consecutive MFMAs then
-// alternate between T accumulators, which is enough to cover the 40-cycle dependent latency of
-// v_mfma_f32_16x16x4_f32.  With T == 1 all m-tiles are interleaved instead.
-template <int MT, int T, typename WP>
-__device__ __forceinline__ void gemm_block(WP wp, const f32x4 (&b)[T], f32x4 (&acc)[MT][T], int nk) {
-    if constexpr (T >= 2) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const f32x4 a = wp[mt * 64];
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (r < nk) {
-#pragma unroll
-                    for (int t = 0; t < T; ++t) acc[mt][t] = MFMA16(a[r], b[t][r], acc[mt][t]);
-                }
-        }
-    } else {
-        f32x4 a[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) a[mt] = wp[mt * 64];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (r < nk) {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int t = 0; t < T; ++t) acc[mt][t] = MFMA16(a[mt][r], b[t][r], acc[mt][t]);
-            }
-    }
-}
-
-// Second half of a node: expansion of the z accumulators in registers, second affine, store.
-// wA2 / b2 point at this node's A2 fragments (+lane) and bias-2 fragment; address space (LDS or
-// global) is resolved after inlining.
-template <int MT1, int MT2, int T, typename WP, typename BP>
-__device__ __forceinline__ void node_tail(const StageParams& P, WP wA2, BP b2, int out_blk, f32x4 (&z)[MT1][T],
-                                          const int (&tile)[T], int lane) {
-    const int g = lane >> 4;
-    if (!P.has_exp) {
-#pragma unroll
-        for (int mt = 0; mt < MT1; ++mt)
-#pragma unroll
-            for (int t = 0; t < T; ++t)
-                if (tile[t] < P.n_tiles) P.out[((size_t)tile[t] * P.nb_out + out_blk + mt) * 64 + lane] = z[mt][t];
-        return;
-    }
-    f32x4 y[MT2][T];
-#pragma unroll
-    for (int mt = 0; mt < MT2; ++mt) {
-        f32x4 bb = *(const f32x4*)(b2 + mt * 16 + g * 4);
-#pragma unroll
-        for (int t = 0; t < T; ++t) y[mt][t] = bb;
-    }
-    const float ex0 = P.expo[0], ex1 = P.expo[1], ex2 = P.expo[2], ex3 = P.expo[3];
-    const uint32_t funcp = P.funcp;
-    const int nf = P.nf;
-#pragma unroll
-    for (int mt1 = 0; mt1 < MT1; ++mt1) {
-        const uint32_t nkp = P.nk2p[mt1];
-        for (int fi = 0; fi < nf; ++fi) {
-            const int nk = (nkp >> (4 * fi)) & 15;
-            if (nk == 0) continue;
-            f32x4 e[T];
-            const int fk = (funcp >> (4 * fi)) & 15;
-            const float ex = fi == 0 ? ex0 : (fi == 1 ? ex1 : (fi == 2 ? ex2 : ex3));
-#pragma unroll
-            for (int t = 0; t < T; ++t) e[t] = apply_func(fk, ex, z[mt1][t]);
-            gemm_block<MT2, T>(wA2 + (mt1 * nf + fi) * MT2 * 64, e, y, nk);
-        }
-    }
-#pragma unroll
-    for (int mt = 0; mt < MT2; ++mt)
-#pragma unroll
-        for (int t = 0; t < T; ++t)
-            if (tile[t] < P.n_tiles) P.out[((size_t)tile[t] * P.nb_out + out_blk + mt) * 64 + lane] = y[mt][t];
 }
 
 // Stages > 0.  A workgroup of NW waves owns NW*T batch tiles and walks a range of nodes; the
@@ -651,636 +503,6 @@ __global__ void __launch_bounds__(256) k_stage_splitm(StageParams P, int mt1n, i
         if (tile[t] < P.n_tiles) P.out[((size_t)tile[t] * P.nb_out + node * P.mto + w) * 64 + lane] = y[t];
 }
 
-// Stage 0: input = caller's row-major sub-image matrix.  The WG stages, for T batch tiles, the
-// column runs its node chunk needs (full 16 B/lane coalesced row segments when alignment allows)
-// into an LDS tile [sub-image][column]; each wave then takes every 4th node of the chunk and
-// reads its receptive field out of LDS (one ds_read_b128 when the four k-steps of a lane are
-// contiguous, e.g. 4-pixel-wide fields), subtracting the node's input mean on the way.
-template <typename XT> struct Vec4Load;
-template <> struct Vec4Load<float> {
-    static __device__ __forceinline__ f32x4 ld(const float* p) { return *(const f32x4*)p; }
-};
-template <> struct Vec4Load<uint8_t> {
-    static __device__ __forceinline__ f32x4 ld(const uint8_t* p) {
-        uint32_t w = *(const uint32_t*)p;
-        f32x4 v;
-        v[0] = (float)(w & 0xff);
-        v[1] = (float)((w >> 8) & 0xff);
-        v[2] = (float)((w >> 16) & 0xff);
-        v[3] = (float)(w >> 24);
-        return v;
-    }
-};
-template <> struct Vec4Load<double> {
-    static __device__ __forceinline__ f32x4 ld(const double* p) {
-        typedef double f64x2 __attribute__((ext_vector_type(2)));
-        f64x2 a = *(const f64x2*)p, b = *(const f64x2*)(p + 2);
-        f32x4 v;
-        v[0] = (float)a[0];
-        v[1] = (float)a[1];
-        v[2] = (float)b[0];
-        v[3] = (float)b[1];
-        return v;
-    }
-};
-
-template <int MT1, int MT2, int T, typename XT>
-__global__ void __launch_bounds__(512) k_stage0(StageParams P) {
-    extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
-    float* lds = (float*)smem;
-    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nthr >> 6, g = lane >> 4, j = lane & 15;
-    const int ci = blockIdx.x % P.n_chunks, grp = blockIdx.x / P.n_chunks;
-    const DChunk ck = P.chunks[ci];
-    int tile[T];
-#pragma unroll
-    for (int t = 0; t < T; ++t) tile[t] = grp * T + t;
-    const XT* x = (const XT*)P.x;
-    const int stride = P.lds_stride;
-    if (P.vec4) {
-        const int pps = ck.n_pieces;             // 16-byte pieces per sub-image
-        const int total = T * 16 * pps;
-        constexpr int NB = 8;                    // loads in flight per thread
-        for (int base = 0; base < total; base += nthr * NB) {
-            f32x4 v[NB];
-            int dsto[NB];
-#pragma unroll
-            for (int k = 0; k < NB; ++k) {
-                const int idx = base + k * nthr + tid;
-                dsto[k] = -1;
-                if (idx < total) {
-                    const int sj = idx / pps, pc = idx - sj * pps;
-                    const int2 pcol = P.piece_col[ck.piece_begin + pc];   // {source column, LDS word offset}
-                    const int tl = tile[0] + sj / 16;
-                    const int64_t row = (int64_t)tl * 16 + (sj & 15);
-                    dsto[k] = sj * stride + pcol.y;
-                    if (tl < P.n_tiles && row < P.n_rows)
-                        v[k] = Vec4Load<XT>::ld(x + row * P.ldx + pcol.x);
-                    else
-                        v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < NB; ++k)
-                if (dsto[k] >= 0) *(f32x4*)(lds + dsto[k]) = v[k];
-        }
-        if (tid < T * 16) lds[tid * stride + stride - 1] = 0.f;
-    } else {
-        for (int t = 0; t < T; ++t)
-            for (int jj = wave; jj < 16; jj += nw) {
-                const int64_t row = (int64_t)tile[t] * 16 + jj;
-                float* dst = lds + (t * 16 + jj) * stride;
-                const bool ok = tile[t] < P.n_tiles && row < P.n_rows;
-                const XT* src = x + (ok ? row : 0) * P.ldx;
-                for (int ri = 0; ri < ck.run_count; ++ri) {
-                    const DRun rn = P.runs[ck.run_begin + ri];
-                    for (int e = lane; e < rn.len; e += 64) dst[rn.lds_off + e] = ok ? (float)src[rn.start + e] : 0.f;
-                }
-                if (lane == 0) dst[stride - 1] = 0.f;  // the "zero column" padded k positions point at
-            }
-    }
-    __syncthreads();
-    for (int ni = ck.node_begin + wave; ni < ck.node_begin + ck.node_count; ni += nw) {
-        const f32x4* wA1 = P.afrag + (size_t)ni * P.node_blocks * 64 + lane;
-        const f32x4* wA2 = wA1 + P.kb1 * MT1 * 64;
-        const float* b1 = P.bias + (size_t)ni * P.bias_floats;
-        f32x4 z[MT1][T];
-#pragma unroll
-        for (int mt = 0; mt < MT1; ++mt) {
-            f32x4 bb = *(const f32x4*)(b1 + mt * 16 + g * 4);
-#pragma unroll
-            for (int t = 0; t < T; ++t) z[mt][t] = bb;
-        }
-        for (int kbi = 0; kbi < P.kb1; ++kbi) {
-            const size_t ent = ((size_t)ni * P.kb1 + kbi) * 16 + g * 4;
-            const i32x4 off = *(const i32x4*)(P.koff + ent);
-            const f32x4 mu = *(const f32x4*)(P.kmean + ent);
-            f32x4 bf[T];
-            if (P.contig4) {
-#pragma unroll
-                for (int t = 0; t < T; ++t) bf[t] = *(const f32x4*)(lds + (t * 16 + j) * stride + off[0]) - mu;
-            } else {
-#pragma unroll
-                for (int t = 0; t < T; ++t) {
-                    const float* base = lds + (t * 16 + j) * stride;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) bf[t][r] = base[off[r]] - mu[r];
-                }
-            }
-            gemm_block<MT1, T>(wA1 + kbi * MT1 * 64, bf, z, kbi == P.kb1 - 1 ? P.nk_last : 4);
-        }
-        node_tail<MT1, MT2, T>(P, wA2, b1 + MT1 * 16, ni * P.mto, z, tile, lane);
-    }
-}
-
-// Stage 0, persistent + software-pipelined variant for small first-layer nodes (one K-block, one
-// tile in and out, <= 2 expansion functions, 16-byte contiguous receptive-field rows): the
-// workgroup owns one node chunk, keeps the weights of its nodes in REGISTERS (2 node slots per
-// wave), and sweeps tile groups part, part + tile_parts, ...  While tile group i is multiplied out
-// of the LDS tile, the row segments of tile group i+1 are already in flight from HBM into registers
-// (8 x 16 B per thread); they are written to LDS after the barrier that ends the compute phase.
-// No load is issued inside the compute phase, so the in-order vmcnt queue never forces the
-// prefetch to land early.
-template <int T, typename XT>
-__global__ void __launch_bounds__(512) k_stage0p(StageParams P) {
-    extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
-    float* lds = (float*)smem;
-    constexpr int NB = 8, NPW = 2;
-    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, nw = nthr >> 6, g = lane >> 4, j = lane & 15;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ci = blockIdx.x % P.n_chunks, part = blockIdx.x / P.n_chunks;
-    const DChunk ck = P.chunks[ci];
-    const XT* x = (const XT*)P.x;
-    const int stride = P.lds_stride;
-    const int n_groups = (P.n_tiles + T - 1) / T;
-    // --- per-thread staging bookkeeping (the same pieces for every tile group)
-    const int pps = ck.n_pieces, total = T * 16 * pps;
-    int p_col[NB], p_dst[NB];   // source column; (sub-image << 24 | LDS word offset) or -1
-#pragma unroll
-    for (int k = 0; k < NB; ++k) {
-        const int idx = k * nthr + tid;
-        p_col[k] = 0;
-        p_dst[k] = -1;
-        if (idx < total) {
-            const int sj = idx / pps, pc = idx - sj * pps;
-            const int2 pcol = P.piece_col[ck.piece_begin + pc];
-            p_col[k] = pcol.x;
-            p_dst[k] = (sj << 24) | (sj * stride + pcol.y);
-        }
-    }
-    // --- weights of this wave's node slots, resident in registers for the whole sweep
-    int w_off[NPW];
-    f32x4 w_mu[NPW], w_a1[NPW], w_a2[NPW][2], w_b1[NPW], w_b2[NPW];
-    bool w_ok[NPW];
-#pragma unroll
-    for (int sl = 0; sl < NPW; ++sl) {
-        const int nl = wave + sl * nw;
-        w_ok[sl] = nl < ck.node_count;
-        const int ni = ck.node_begin + (w_ok[sl] ? nl : 0);
-        const size_t ent = (size_t)ni * 16 + g * 4;       // kb1 == 1
-        w_off[sl] = P.koff[ent];
-        w_mu[sl] = *(const f32x4*)(P.kmean + ent);
-        const f32x4* wp = P.afrag + (size_t)ni * P.node_blocks * 64 + lane;
-        w_a1[sl] = wp[0];
-        w_a2[sl][0] = wp[64];
-        w_a2[sl][1] = P.nf > 1 ? wp[128] : wp[64];
-        const float* bp = P.bias + (size_t)ni * P.bias_floats + g * 4;
-        w_b1[sl] = *(const f32x4*)bp;
-        w_b2[sl] = *(const f32x4*)(bp + 16);
-    }
-    const int nk1 = P.nk_last;
-    const int nk2a = P.nk2p[0] & 15, nk2b = (P.nk2p[0] >> 4) & 15;
-    const int fk0 = P.funcp & 15, fk1 = (P.funcp >> 4) & 15;
-    const float ex0 = P.expo[0], ex1 = P.expo[1];
-
-    auto fetch = [&](int grp, f32x4 (&v)[NB]) {
-#pragma unroll
-        for (int k = 0; k < NB; ++k) {
-            const int64_t row = (int64_t)grp * (T * 16) + (p_dst[k] >> 24);
-            if (p_dst[k] >= 0 && row < P.n_rows)
-                v[k] = Vec4Load<XT>::ld(x + row * P.ldx + p_col[k]);
-            else
-                v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    };
-    f32x4 v[NB];
-    if (part < n_groups) fetch(part, v);
-    for (int grp = part; grp < n_groups; grp += P.tile_parts) {
-#pragma unroll
-        for (int k = 0; k < NB; ++k)
-            if (p_dst[k] >= 0) *(f32x4*)(lds + (p_dst[k] & 0xffffff)) = v[k];
-        if (tid < T * 16) lds[tid * stride + stride - 1] = 0.f;
-        __syncthreads();
-        if (grp + P.tile_parts < n_groups) fetch(grp + P.tile_parts, v);
-        int tile[T];
-#pragma unroll
-        for (int t = 0; t < T; ++t) tile[t] = grp * T + t;
-#pragma unroll
-        for (int sl = 0; sl < NPW; ++sl) {
-            if (!w_ok[sl]) continue;
-            const int ni = ck.node_begin + wave + sl * nw;
-            f32x4 z[1][T], y[1][T], bf[T];
-#pragma unroll
-            for (int t = 0; t < T; ++t) {
-                bf[t] = *(const f32x4*)(lds + (t * 16 + j) * stride + w_off[sl]) - w_mu[sl];
-                z[0][t] = w_b1[sl];
-                y[0][t] = w_b2[sl];
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (r < nk1) {
-#pragma unroll
-                    for (int t = 0; t < T; ++t) z[0][t] = MFMA16(w_a1[sl][r], bf[t][r], z[0][t]);
-                }
-            {
-                f32x4 e[T];
-#pragma unroll
-                for (int t = 0; t < T; ++t) e[t] = apply_func(fk0, ex0, z[0][t]);
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (r < nk2a) {
-#pragma unroll
-                        for (int t = 0; t < T; ++t) y[0][t] = MFMA16(w_a2[sl][0][r], e[t][r], y[0][t]);
-                    }
-            }
-            if (P.nf > 1) {
-                f32x4 e[T];
-#pragma unroll
-                for (int t = 0; t < T; ++t) e[t] = apply_func(fk1, ex1, z[0][t]);
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (r < nk2b) {
-#pragma unroll
-                        for (int t = 0; t < T; ++t) y[0][t] = MFMA16(w_a2[sl][1][r], e[t][r], y[0][t]);
-                    }
-            }
-#pragma unroll
-            for (int t = 0; t < T; ++t)
-                if (tile[t] < P.n_tiles) P.out[((size_t)tile[t] * P.nb_out + ni) * 64 + lane] = y[0][t];
-        }
-        __syncthreads();
-    }
-}
-
-// Stages 0 AND 1 in one persistent kernel (the U11L front end): same structure as k_stage0p, but a
-// wave's two node slots are ADJACENT layer-0 nodes 2w, 2w+1 — the two children of layer-1 node w of
-// the chunk — so their output accumulators are, in registers, the two K-blocks of that layer-1
-// node's first affine.  Layer-1 weights (4 + 8 fragment blocks) are register resident too.  The
-// layer-0 activation (64 KiB per sub-image written and read back) never exists in memory.
-// Requirements checked on the host: layer 0 as for k_stage0p; layer-1 node n reads exactly the
-// blocks of layer-0 nodes 2n and 2n+1; both layer-1 affines have <= 32 outputs; same <= 2 functions.
-template <typename XT, bool STAMP = false>
-__global__ void __launch_bounds__(512) k_stage01p(StageParams P, StageParams Q) {
-    extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
-    float* lds = (float*)smem;
-    constexpr int T = 2, NB = 4, NPW = 2;
-    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, g = lane >> 4, j = lane & 15;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ci = blockIdx.x % P.n_chunks, part = blockIdx.x / P.n_chunks;
-    const DChunk ck = P.chunks[ci];
-    const XT* x = (const XT*)P.x;
-    const int stride = P.lds_stride;
-    const int n_groups = (P.n_tiles + T - 1) / T;
-    const int pps = ck.n_pieces, total = T * 16 * pps;
-    const XT* p_src[NB];   // address of the piece in tile group 0; a group advances every piece by T*16 rows
-    int p_dst[NB];
-#pragma unroll
-    for (int k = 0; k < NB; ++k) {
-        const int idx = k * nthr + tid;
-        p_src[k] = x;
-        p_dst[k] = -1;
-        if (idx < total) {
-            const int sj = idx / pps, pc = idx - sj * pps;
-            const int2 pcol = P.piece_col[ck.piece_begin + pc];
-            p_src[k] = x + (int64_t)sj * P.ldx + pcol.x;
-            p_dst[k] = (sj << 24) | (sj * stride + pcol.y);
-        }
-    }
-    const int64_t grp_step = (int64_t)(T * 16) * P.ldx;
-    // layer-0 weights of the two slots
-    int w_off[NPW];
-    f32x4 w_mu[NPW], w_a1[NPW], w_a2[NPW][2], w_b1[NPW], w_b2[NPW];
-    const bool w_ok = 2 * wave + 1 < ck.node_count;    // both children present (chunks hold whole pairs)
-#pragma unroll
-    for (int sl = 0; sl < NPW; ++sl) {
-        const int ni = ck.node_begin + (w_ok ? 2 * wave + sl : 0);
-        const size_t ent = (size_t)ni * 16 + g * 4;
-        w_off[sl] = P.koff[ent];
-        w_mu[sl] = *(const f32x4*)(P.kmean + ent);
-        const f32x4* wp = P.afrag + (size_t)ni * P.node_blocks * 64 + lane;
-        w_a1[sl] = wp[0];
-        w_a2[sl][0] = wp[64];
-        w_a2[sl][1] = P.nf > 1 ? wp[128] : wp[64];
-        const float* bp = P.bias + (size_t)ni * P.bias_floats + g * 4;
-        w_b1[sl] = *(const f32x4*)bp;
-        w_b2[sl] = *(const f32x4*)(bp + 16);
-    }
-    // layer-1 node of this wave: A1 [kb 0..1][mt 0..1], A2 [mt1 0..1][fi 0..1][mt2 0..1], biases
-    const int n1 = (ck.node_begin >> 1) + (w_ok ? wave : 0);
-    f32x4 q_a1[2][2], q_a2[2][2][2], q_b1[2], q_b2[2];
-    {
-        const f32x4* wq = Q.afrag + (size_t)n1 * Q.node_blocks * 64 + lane;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) q_a1[kb][mt] = wq[(kb * 2 + mt) * 64];
-        const f32x4* wq2 = wq + Q.kb1 * 2 * 64;
-#pragma unroll
-        for (int m1 = 0; m1 < 2; ++m1)
-#pragma unroll
-            for (int fi = 0; fi < 2; ++fi)
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) q_a2[m1][fi][mt] = wq2[((m1 * Q.nf + (fi < Q.nf ? fi : 0)) * 2 + mt) * 64];
-        const float* bq = Q.bias + (size_t)n1 * Q.bias_floats + g * 4;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            q_b1[mt] = *(const f32x4*)(bq + mt * 16);
-            q_b2[mt] = *(const f32x4*)(bq + 32 + mt * 16);
-        }
-    }
-    const int fk0 = P.funcp & 15, fk1 = (P.funcp >> 4) & 15;
-    const float ex0 = P.expo[0], ex1 = P.expo[1];
-    const int qfk0 = Q.funcp & 15, qfk1 = (Q.funcp >> 4) & 15;
-    const float qex0 = Q.expo[0], qex1 = Q.expo[1];
-
-    auto fetch = [&](int grp, f32x4 (&v)[NB]) {
-        const int64_t goff = (int64_t)grp * grp_step;            // wave-uniform
-        const int64_t rows_left = P.n_rows - (int64_t)grp * (T * 16);
-#pragma unroll
-        for (int k = 0; k < NB; ++k) {
-            if (p_dst[k] >= 0 && (p_dst[k] >> 24) < rows_left)
-                v[k] = Vec4Load<XT>::ld(p_src[k] + goff);
-            else
-                v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    };
-    f32x4 v[NB];
-    if (part < n_groups) fetch(part, v);
-    // two LDS tiles, used alternately: one barrier per tile group is enough (a wave that writes tile
-    // i+1 has passed barrier i, i.e. every wave has finished reading tile i-1, which shares its buffer)
-    const int buf_words = T * 16 * stride;
-    float* lds0 = lds;
-    int flip = 0;
-    unsigned long long t_w = 0, t_f = 0, t_l0 = 0, t_l1 = 0, t_all0 = 0, rt0 = 0, ts = 0;
-    int n_it = 0;
-    if (STAMP) {
-        t_all0 = stamp_now();
-        rt0 = __builtin_amdgcn_s_memrealtime();
-    }
-    for (int grp = part; grp < n_groups; grp += P.tile_parts) {
-        if (STAMP) ts = stamp_now();
-        lds = lds0 + flip * buf_words;
-        flip ^= 1;
-#pragma unroll
-        for (int k = 0; k < NB; ++k)
-            if (p_dst[k] >= 0) *(f32x4*)(lds + (p_dst[k] & 0xffffff)) = v[k];
-        if (tid < T * 16) lds[tid * stride + stride - 1] = 0.f;
-        __syncthreads();
-        if (STAMP) { unsigned long long t = stamp_now(); t_w += t - ts; ts = t; }
-        if (grp + P.tile_parts < n_groups) fetch(grp + P.tile_parts, v);
-        if (STAMP) { unsigned long long t = stamp_now(); t_f += t - ts; ts = t; }
-        if (w_ok) {
-            int tile[T];
-#pragma unroll
-            for (int t = 0; t < T; ++t) tile[t] = grp * T + t;
-            // ---- layer 0: two children
-            f32x4 y0[NPW][T];
-#pragma unroll
-            for (int sl = 0; sl < NPW; ++sl) {
-                f32x4 z[T], bf[T];
-#pragma unroll
-                for (int t = 0; t < T; ++t) {
-                    bf[t] = *(const f32x4*)(lds + (t * 16 + j) * stride + w_off[sl]) - w_mu[sl];
-                    z[t] = w_b1[sl];
-                    y0[sl][t] = w_b2[sl];
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int t = 0; t < T; ++t) z[t] = MFMA16(w_a1[sl][r], bf[t][r], z[t]);
-                {
-                    f32x4 e[T];
-#pragma unroll
-                    for (int t = 0; t < T; ++t) e[t] = apply_func(fk0, ex0, z[t]);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-#pragma unroll
-                        for (int t = 0; t < T; ++t) y0[sl][t] = MFMA16(w_a2[sl][0][r], e[t][r], y0[sl][t]);
-                }
-                {
-                    f32x4 e[T];
-#pragma unroll
-                    for (int t = 0; t < T; ++t) e[t] = apply_func(fk1, ex1, z[t]);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-#pragma unroll
-                        for (int t = 0; t < T; ++t) y0[sl][t] = MFMA16(w_a2[sl][1][r], e[t][r], y0[sl][t]);
-                }
-            }
-            if (STAMP) { unsigned long long t = stamp_now(); t_l0 += t - ts; ts = t; }
-            // ---- layer 1: K-blocks of the first affine are the children's accumulators
-            f32x4 z1[2][T], y1[2][T];
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int t = 0; t < T; ++t) {
-                    z1[mt][t] = q_b1[mt];
-                    y1[mt][t] = q_b2[mt];
-                }
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                        for (int t = 0; t < T; ++t) z1[mt][t] = MFMA16(q_a1[kb][mt][r], y0[kb][t][r], z1[mt][t]);
-#pragma unroll
-            for (int fi = 0; fi < 2; ++fi) {        // z tile 0: full, branch-free
-                f32x4 e[T];
-#pragma unroll
-                for (int t = 0; t < T; ++t) e[t] = apply_func(fi == 0 ? qfk0 : qfk1, fi == 0 ? qex0 : qex1, z1[0][t]);
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                        for (int t = 0; t < T; ++t) y1[mt][t] = MFMA16(q_a2[0][fi][mt][r], e[t][r], y1[mt][t]);
-            }
-#pragma unroll
-            for (int fi = 0; fi < 2; ++fi) {        // z tile 1: partial (runtime k-step count)
-                const int nk = (int)((Q.nk2p[1] >> (4 * fi)) & 15);
-                f32x4 e[T];
-#pragma unroll
-                for (int t = 0; t < T; ++t) e[t] = apply_func(fi == 0 ? qfk0 : qfk1, fi == 0 ? qex0 : qex1, z1[1][t]);
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (r < nk) {
-#pragma unroll
-                        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                            for (int t = 0; t < T; ++t) y1[mt][t] = MFMA16(q_a2[1][fi][mt][r], e[t][r], y1[mt][t]);
-                    }
-            }
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int t = 0; t < T; ++t)
-                    if (tile[t] < P.n_tiles) Q.out[((size_t)tile[t] * Q.nb_out + (size_t)n1 * Q.mto + mt) * 64 + lane] = y1[mt][t];
-            if (STAMP) { unsigned long long t = stamp_now(); t_l1 += t - ts; ts = t; ++n_it; }
-        }
-    }
-    if (STAMP && lane == 0 && P.stamps) {
-        unsigned long long* o = P.stamps + ((size_t)blockIdx.x * 8 + wave) * 8;
-        o[0] = t_w; o[1] = t_f; o[2] = t_l0; o[3] = t_l1;
-        o[4] = stamp_now() - t_all0;
-        o[5] = __builtin_amdgcn_s_memrealtime() - rt0;
-        o[6] = (unsigned long long)n_it;
-    }
-}
-
-// Row-major input -> fragment order (used in front of a first layer of iGSFA nodes, whose kernel
-// reads fragment-order blocks like every later layer).  One wave per (batch tile, block): lane (g, j)
-// gathers the four columns of its four k-steps for sub-image j.
-template <typename XT>
-__global__ void __launch_bounds__(256) k_im2frag(const XT* __restrict__ x, int64_t ldx, int64_t n_rows, int n_tiles, int nb,
-                                                 const int32_t* __restrict__ gcol, f32x4* __restrict__ out, int vec4) {
-    const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
-    const int64_t wid = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (wid >= (int64_t)n_tiles * nb) return;
-    const int tile = (int)(wid / nb), blk = (int)(wid - (int64_t)tile * nb);
-    const int64_t row = (int64_t)tile * 16 + j;
-    const i32x4 c = *(const i32x4*)(gcol + (size_t)blk * 16 + g * 4);
-    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (row < n_rows) {
-        const XT* xr = x + row * ldx;
-        if (vec4 && c[0] >= 0 && c[3] == c[0] + 3) {     // four contiguous, 16-byte aligned columns
-            v = Vec4Load<XT>::ld(xr + c[0]);
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (c[r] >= 0) v[r] = (float)xr[c[r]];
-        }
-    }
-    out[(size_t)wid * 64 + lane] = v;
-}
-
-// A layer of iGSFA nodes.  Same workgroup structure as k_stage (node
-// weights once into LDS, persistent sweep over tile groups), three chained GEMMs per node, all
-// operands in registers:
-//   x0[kb] = input fragments - mean                                   (K-blocks of the node input)
-//   y[ms] += W1[fi][kb][ms] * f_fi(x0[kb])          s = scaled slow features (rows of y tiles < MS)
-//   x0[kb] = x0[kb] + bias_r[kb] + W2[kb][ms] * y[ms]                 r = x0 - lr(s): the input fragment
-//                                                                     IS the C operand (same layout)
-//   y[mo] += W3[kb][mo] * x0[kb]                    q = pca(r) lands in the remaining rows of y
-// Output tiles hold [s, q] in the caller's column order.
-template <int MS, int MO, int T>
-__global__ void __launch_bounds__(512, 2) k_igsfa(StageParams P) {
-    extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
-    constexpr int KBM = 8;   // K-blocks of a node input (<= 128 inputs)
-    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, nw = nthr >> 6, g = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // a workgroup owns a group of `nodes_per_group` consecutive nodes (their weights fit LDS together)
-    const int npg = P.nodes_per_group;
-    const int grp_id = blockIdx.x % P.n_chunks, part = blockIdx.x / P.n_chunks;
-    const int g0 = grp_id * npg, gn = min(npg, P.n_nodes - g0);
-    float* sb = (float*)(smem + (size_t)npg * P.node_blocks * 64);
-    int2* stab = (int2*)(sb + npg * P.bias_floats);
-    {
-        const f32x4* src = P.afrag + (size_t)g0 * P.node_blocks * 64;
-        const int nvec = gn * P.node_blocks * 64;
-        int i = tid;
-        for (; i + 3 * nthr < nvec; i += 4 * nthr) {
-            f32x4 v0 = src[i], v1 = src[i + nthr], v2 = src[i + 2 * nthr], v3 = src[i + 3 * nthr];
-            smem[i] = v0;
-            smem[i + nthr] = v1;
-            smem[i + 2 * nthr] = v2;
-            smem[i + 3 * nthr] = v3;
-        }
-        for (; i < nvec; i += nthr) smem[i] = src[i];
-        const float* bsrc = P.bias + (size_t)g0 * P.bias_floats;
-        for (int k = tid; k < gn * P.bias_floats; k += nthr) sb[k] = bsrc[k];
-        const int2* tsrc = P.kb1tab + (size_t)g0 * P.kb1;
-        for (int k = tid; k < gn * P.kb1; k += nthr) stab[k] = tsrc[k];
-    }
-    __syncthreads();
-    const int kb1 = P.kb1, nf = P.nf;
-    for (int grp = part; grp < P.tile_groups; grp += P.tile_parts) {
-        int tile[T];
-#pragma unroll
-        for (int t = 0; t < T; ++t) tile[t] = (grp * nw + wave) * T + t;
-        if (tile[0] >= P.n_tiles) break;
-      for (int ln = 0; ln < gn; ++ln) {
-        const int node = g0 + ln;
-        const f32x4* w1 = smem + (size_t)ln * P.node_blocks * 64 + lane;   // [fi][kb][ms]
-        const f32x4* w2 = w1 + (size_t)nf * kb1 * MS * 64;              // [kb][ms]
-        const f32x4* w3 = w2 + (size_t)kb1 * MS * 64;                   // [kb][mo]
-        const float* by = sb + ln * P.bias_floats;                      // [MO][16]
-        const float* br = by + MO * 16;                                 // [kb][16]
-        const float* mu = br + kb1 * 16;                                // [kb][16]
-        const int2* ktab = stab + ln * kb1;
-        f32x4 x0[KBM][T];
-        int nk1[KBM];
-#pragma unroll
-        for (int kb = 0; kb < KBM; ++kb) {
-            nk1[kb] = 0;
-            if (kb < kb1) {
-                const int2 e = ktab[kb];
-                const int sbk = __builtin_amdgcn_readfirstlane(e.x);
-                nk1[kb] = __builtin_amdgcn_readfirstlane(e.y);
-                const f32x4 m = *(const f32x4*)(mu + kb * 16 + g * 4);
-#pragma unroll
-                for (int t = 0; t < T; ++t) {
-                    const int tl = tile[t] < P.n_tiles ? tile[t] : tile[0];
-                    x0[kb][t] = P.in[((size_t)tl * P.nb_in + sbk) * 64 + lane] - m;
-                }
-            }
-        }
-        f32x4 y[MO][T];
-#pragma unroll
-        for (int mo = 0; mo < MO; ++mo) {
-            const f32x4 bb = *(const f32x4*)(by + mo * 16 + g * 4);
-#pragma unroll
-            for (int t = 0; t < T; ++t) y[mo][t] = bb;
-        }
-        // G1: slow features from the expanded input
-        for (int fi = 0; fi < nf; ++fi) {
-            const int fk = (P.funcp >> (4 * fi)) & 15;
-            const float ex = P.expo[fi];
-#pragma unroll
-            for (int kb = 0; kb < KBM; ++kb) {
-                if (kb >= kb1) continue;
-                f32x4 e[T];
-#pragma unroll
-                for (int t = 0; t < T; ++t) e[t] = apply_func(fk, ex, x0[kb][t]);
-                const f32x4* wp = w1 + ((size_t)(fi * kb1 + kb) * MS) * 64;
-#pragma unroll
-                for (int ms = 0; ms < MS; ++ms) {      // only the tiles that hold slow features
-                    const f32x4 a = wp[ms * 64];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (r < nk1[kb]) {
-#pragma unroll
-                            for (int t = 0; t < T; ++t) y[ms][t] = MFMA16(a[r], e[t][r], y[ms][t]);
-                        }
-                }
-            }
-        }
-        // G2: residual r = x0 - lr(s), accumulated into the input fragments
-        if (P.ig_has_lr) {
-#pragma unroll
-            for (int kb = 0; kb < KBM; ++kb) {
-                if (kb >= kb1) continue;
-                const f32x4 bb = *(const f32x4*)(br + kb * 16 + g * 4);
-#pragma unroll
-                for (int t = 0; t < T; ++t) x0[kb][t] += bb;
-#pragma unroll
-                for (int ms = 0; ms < MS; ++ms) {
-                    const f32x4 a = w2[((size_t)kb * MS + ms) * 64];
-                    const int nks = (P.nk2p[0] >> (4 * ms)) & 15;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (r < nks) {
-#pragma unroll
-                            for (int t = 0; t < T; ++t) x0[kb][t] = MFMA16(a[r], y[ms][t][r], x0[kb][t]);
-                        }
-                }
-            }
-        }
-        // G3: q = pca(r) into the remaining rows of the output tiles
-#pragma unroll
-        for (int kb = 0; kb < KBM; ++kb) {
-            if (kb >= kb1) continue;
-            gemm_block<MO, T>(w3 + ((size_t)kb * MO) * 64, x0[kb], y, nk1[kb]);
-        }
-#pragma unroll
-        for (int mo = 0; mo < MO; ++mo)
-#pragma unroll
-            for (int t = 0; t < T; ++t)
-                if (tile[t] < P.n_tiles) P.out[((size_t)tile[t] * P.nb_out + (size_t)node * MO + mo) * 64 + lane] = y[mo][t];
-      }
-    }
-}
-
 // Fragment order -> caller's row-major y (first y_cols columns).
 template <typename YT>
 __global__ void k_unpack(const float* __restrict__ act, int nb, const int32_t* __restrict__ col_base, YT* __restrict__ y,
@@ -1296,8 +518,6 @@ __global__ void k_unpack(const float* __restrict__ act, int nb, const int32_t* _
 }
 
 // ---- launch tables -----------------------------------------------------------------------------
-typedef void (*StageFn)(StageParams);
-typedef void (*StageFn2)(StageParams, StageParams);
 
 template <int MT1, int MT2>
 StageFn pick_stage_t(int T) {
@@ -1322,56 +542,6 @@ StageFn pick_stage(int mt1, int mt2, int T) {
     }
 }
 
-template <int MT1, int MT2, typename XT>
-StageFn pick_stage0_t(int T) {
-    if (T == 4) return k_stage0<MT1, MT2, 4, XT>;
-    return k_stage0<MT1, MT2, 1, XT>;
-}
-template <int MT1, typename XT>
-StageFn pick_stage0_m2(int mt2, int T) {
-    switch (mt2) {
-        case 1: return pick_stage0_t<MT1, 1, XT>(T);
-        case 2: return pick_stage0_t<MT1, 2, XT>(T);
-        case 3: return pick_stage0_t<MT1, 3, XT>(T);
-        default: return pick_stage0_t<MT1, 4, XT>(T);
-    }
-}
-template <typename XT>
-StageFn pick_stage0_x(int mt1, int mt2, int T) {
-    switch (mt1) {
-        case 1: return pick_stage0_m2<1, XT>(mt2, T);
-        case 2: return pick_stage0_m2<2, XT>(mt2, T);
-        case 3: return pick_stage0_m2<3, XT>(mt2, T);
-        default: return pick_stage0_m2<4, XT>(mt2, T);
-    }
-}
-StageFn pick_stage0(int mt1, int mt2, int T, int x_dtype) {
-    switch (x_dtype) {
-        case HG_U8: return pick_stage0_x<uint8_t>(mt1, mt2, T);
-        case HG_F32: return pick_stage0_x<float>(mt1, mt2, T);
-        default: return pick_stage0_x<double>(mt1, mt2, T);
-    }
-}
-
-template <int MS, int MO>
-StageFn pick_igsfa_t(int T) {
-    if (T == 2) return k_igsfa<MS, MO, 2>;
-    return k_igsfa<MS, MO, 1>;
-}
-StageFn pick_igsfa(int ms, int mo, int T) {   // ms <= mo (the slow features are a prefix of the output)
-    switch (ms * 10 + mo) {
-        case 11: return pick_igsfa_t<1, 1>(T);
-        case 12: return pick_igsfa_t<1, 2>(T);
-        case 13: return pick_igsfa_t<1, 3>(T);
-        case 14: return pick_igsfa_t<1, 4>(T);
-        case 22: return pick_igsfa_t<2, 2>(T);
-        case 23: return pick_igsfa_t<2, 3>(T);
-        case 24: return pick_igsfa_t<2, 4>(T);
-        case 33: return pick_igsfa_t<3, 3>(T);
-        case 34: return pick_igsfa_t<3, 4>(T);
-        default: return pick_igsfa_t<4, 4>(T);
-    }
-}
 
 // ---- the executor --------------------------------------------------------------------------------
 inline int q_of_row(int i) { return 4 * (i & 3) + (i >> 2); }  // tile row -> tile-local feature (involution)
@@ -1727,16 +897,9 @@ public:
             };
             StageParams P = base_params(s, cur, nxt);
             if (s.kind == 1) {        // row-major input -> fragment order
-                const int64_t waves = (int64_t)n_tiles * s.nb_out;
-                const unsigned grid = (unsigned)((waves + 3) / 4);
                 const size_t esz0 = dtype_size(x_dtype), al0 = x_dtype == HG_U8 ? 4 : 16;
                 const int v4 = (s.vec_ok && ldx % 4 == 0 && ((uintptr_t)x % al0) == 0 && (ldx * esz0) % al0 == 0) ? 1 : 0;
-                if (x_dtype == HG_U8)
-                    hipLaunchKernelGGL(k_im2frag<uint8_t>, grid, 256, 0, st, (const uint8_t*)x, ldx, n, n_tiles, s.nb_out, (const int32_t*)s.d_gcol.p, nxt, v4);
-                else if (x_dtype == HG_F32)
-                    hipLaunchKernelGGL(k_im2frag<float>, grid, 256, 0, st, (const float*)x, ldx, n, n_tiles, s.nb_out, (const int32_t*)s.d_gcol.p, nxt, v4);
-                else
-                    hipLaunchKernelGGL(k_im2frag<double>, grid, 256, 0, st, (const double*)x, ldx, n, n_tiles, s.nb_out, (const int32_t*)s.d_gcol.p, nxt, v4);
+                launch_im2frag(x, x_dtype, ldx, n, n_tiles, s.nb_out, (const int32_t*)s.d_gcol.p, nxt, v4, st);
                 std::swap(cur, nxt);
                 if (ev) HG_HIP(hipEventRecord(ev[e++], st));
                 continue;
@@ -1754,7 +917,7 @@ public:
                 P.n_chunks = (s.n_nodes + npg - 1) / npg;
                 P.tile_parts = std::max(1, std::min(P.tile_groups, 512 / std::max(1, P.n_chunks)));
                 const size_t lds_bytes = (size_t)npg * (s.node_blocks * 1024 + (size_t)s.bias_floats * 4 + (size_t)s.kb1 * 8);
-                StageFn fn = pick_igsfa(s.mt1, s.mt2, T);
+                StageFn fn = pick_igsfa(s.mt1, s.mt2, T, s.kb1);
                 set_lds_limit(fn, lds_bytes);
                 hipLaunchKernelGGL(fn, (unsigned)(P.n_chunks * P.tile_parts), nw * 64, lds_bytes, st, P);
                 std::swap(cur, nxt);
@@ -1783,8 +946,7 @@ public:
                 if (fuse01_ && P.vec4 && n_tiles >= 2) {
                     // layers 0 and 1 in one persistent kernel; layer 1 writes where its own launch would
                     StageParams Q = base_params(stages_[1], nullptr, cur);
-                    StageFn2 fn = x_dtype == HG_U8 ? (StageFn2)k_stage01p<uint8_t>
-                                  : x_dtype == HG_F32 ? (StageFn2)k_stage01p<float> : (StageFn2)k_stage01p<double>;
+                    StageFn2 fn = pick_stage01p(x_dtype, false);
                     const size_t lds2 = (size_t)2 * 2 * 16 * s.lds_stride * 4;   // two tiles of T = 2 batch tiles
                     const int thr01 = 64 * std::max(1, (s.max_chunk_nodes + 1) / 2);   // one wave per pair of layer-0 nodes
                     const int groups2 = (n_tiles + 1) / 2;
@@ -1804,7 +966,7 @@ public:
                     P.tile_parts = std::max(1, std::min(groups2, 256 * occ / std::max(1, P.n_chunks)));
                     const char* stamp_env = getenv("HIGSFA_STAMP");
                     if (stamp_env && atoi(stamp_env) == 0 && x_dtype == HG_F32) {
-                        fn = (StageFn2)k_stage01p<float, true>;
+                        fn = pick_stage01p(HG_F32, true);
                         stamp_blocks_ = P.n_chunks * P.tile_parts;
                         stamp_buf_.alloc((size_t)stamp_blocks_ * 8 * 8 * 8);
                         HG_HIP(hipMemsetAsync(stamp_buf_.p, 0, stamp_buf_.bytes, st));
@@ -1833,8 +995,7 @@ public:
                 const bool persistent = T == 4 && P.vec4 && s.contig4 && s.has_exp && s.mt1 == 1 && s.mt2 == 1 && s.kb1 == 1 &&
                                         s.nf <= 2 && s.max_chunk_nodes <= 16 && 64 * s.max_chunk_pieces <= 8 * 512;
                 if (persistent) {
-                    StageFn fn = x_dtype == HG_U8 ? (StageFn)k_stage0p<4, uint8_t>
-                                 : x_dtype == HG_F32 ? (StageFn)k_stage0p<4, float> : (StageFn)k_stage0p<4, double>;
+                    StageFn fn = pick_stage0p(x_dtype);
                     const int occ = resident_blocks(fn, 512, lds_bytes);
                     int parts = std::max(1, std::min(groups, 256 * occ / std::max(1, P.n_chunks)));
                     P.tile_parts = parts;

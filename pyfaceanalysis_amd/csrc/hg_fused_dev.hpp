@@ -1,0 +1,203 @@
+// Device-side definitions shared by the fused-plan translation units (hg_fused.hip: planner, executor,
+// mid/top layer kernels; hg_fused_front.hip: first-layer kernels; hg_fused_igsfa.hip: iGSFA kernels).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "hg_common.hpp"
+
+namespace hg {
+namespace fused {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kMaxMT = 4;            // up to 64 outputs per affine in the fused plan
+
+// Every stage is padded to a UNIFORM node structure (same K-block count, tile counts and
+// expansion list for all its nodes; missing pieces are zero weights), so all weight / bias
+// addresses are arithmetic on the node index and the only per-node table is the list of source
+// blocks of GEMM 1.
+constexpr int kMaxFuncs = 4;
+
+struct DChunk {   // stage 0: a group of consecutive nodes whose input columns share one LDS tile
+    int32_t node_begin, node_count, run_begin, run_count, n_cols, piece_begin, n_pieces, pad1;
+};
+struct DRun {
+    int32_t start, len, lds_off, pad;
+};
+
+struct StageParams {
+    const f32x4* afrag;   // [node][ A1: kb1 x MT1 | A2: MT1 x nf x MT2 ] blocks of 64 x f32x4
+    const float* bias;    // [node][ (MT1 + MT2) x 16 ]
+    const int2* kb1tab;   // [node][kb1] {source block, k-steps}           (stages > 0)
+    const f32x4* in;      // input activation, fragment order               (stages > 0)
+    f32x4* out;
+    int32_t n_nodes, kb1, nf, has_exp;
+    int32_t node_blocks, bias_floats, n_tiles, nb_in, nb_out, mto;
+    int32_t nodes_per_group, nodes_per_wg, n_chunks, tile_groups, tile_parts;
+    uint32_t nk2p[kMaxMT];     // per z tile: 4 bits of k-steps per expansion function
+    uint32_t funcp;            // 4 bits of ExpKind per expansion function
+    float expo[kMaxFuncs];
+    // stage 0
+    const DChunk* chunks;
+    const DRun* runs;
+    const int2* piece_col;     // per chunk piece (4 columns) -> {first source column, LDS word offset}
+    const int32_t* koff;       // [node*kb1 + kb][g][r] LDS word offsets
+    const float* kmean;        // same shape: means subtracted by the loader
+    const void* x;
+    int64_t ldx, n_rows;
+    int32_t lds_stride, nk_last, vec4, contig4;
+    int32_t ig_has_lr;
+    unsigned long long* stamps;   // diagnostic build only (HIGSFA_STAMP): per-wave cycle stamps
+};
+
+__device__ __forceinline__ unsigned long long stamp_now() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+
+__device__ __forceinline__ float pow_abs(float v, float p) {
+    // |v|^p = exp2(p * log2|v|); v = 0 -> log2 = -inf -> exp2 = 0 exactly
+    return __builtin_amdgcn_exp2f(p * __builtin_amdgcn_logf(__builtin_fabsf(v)));
+}
+
+__device__ __forceinline__ f32x4 apply_func(int func, float expo, f32x4 z) {
+    f32x4 e;
+    if (func == (int)E_IDENTITY) {
+        e = z;
+    } else if (func == (int)E_ABS_POW) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) e[r] = pow_abs(z[r], expo);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) e[r] = __builtin_copysignf(pow_abs(z[r], expo), z[r]);
+    }
+    return e;
+}
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// One K-block: acc[mt][t] += A[mt] (16 x 16, four k-steps) * B[t].  `wp` points at the block's first
+// A fragment (+lane); fragments of consecutive m-tiles are 64 f32x4 apart.  With T >= 2 the A
+// fragment is read one m-tile at a time (4 live registers instead of 4*MT): consecutive MFMAs then
+// alternate between T accumulators, which is enough to cover the 40-cycle dependent latency of
+// v_mfma_f32_16x16x4_f32.  With T == 1 all m-tiles are interleaved instead.
+template <int MT, int T, typename WP>
+__device__ __forceinline__ void gemm_block(WP wp, const f32x4 (&b)[T], f32x4 (&acc)[MT][T], int nk) {
+    if constexpr (T >= 2) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const f32x4 a = wp[mt * 64];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (r < nk) {
+#pragma unroll
+                    for (int t = 0; t < T; ++t) acc[mt][t] = MFMA16(a[r], b[t][r], acc[mt][t]);
+                }
+        }
+    } else {
+        f32x4 a[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[mt] = wp[mt * 64];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (r < nk) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int t = 0; t < T; ++t) acc[mt][t] = MFMA16(a[mt][r], b[t][r], acc[mt][t]);
+            }
+    }
+}
+
+// Second half of a node: expansion of the z accumulators in registers, second affine, store.
+// wA2 / b2 point at this node's A2 fragments (+lane) and bias-2 fragment; address space (LDS or
+// global) is resolved after inlining.
+template <int MT1, int MT2, int T, typename WP, typename BP>
+__device__ __forceinline__ void node_tail(const StageParams& P, WP wA2, BP b2, int out_blk, f32x4 (&z)[MT1][T],
+                                          const int (&tile)[T], int lane) {
+    const int g = lane >> 4;
+    if (!P.has_exp) {
+#pragma unroll
+        for (int mt = 0; mt < MT1; ++mt)
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+                if (tile[t] < P.n_tiles) P.out[((size_t)tile[t] * P.nb_out + out_blk + mt) * 64 + lane] = z[mt][t];
+        return;
+    }
+    f32x4 y[MT2][T];
+#pragma unroll
+    for (int mt = 0; mt < MT2; ++mt) {
+        f32x4 bb = *(const f32x4*)(b2 + mt * 16 + g * 4);
+#pragma unroll
+        for (int t = 0; t < T; ++t) y[mt][t] = bb;
+    }
+    const float ex0 = P.expo[0], ex1 = P.expo[1], ex2 = P.expo[2], ex3 = P.expo[3];
+    const uint32_t funcp = P.funcp;
+    const int nf = P.nf;
+#pragma unroll
+    for (int mt1 = 0; mt1 < MT1; ++mt1) {
+        const uint32_t nkp = P.nk2p[mt1];
+        for (int fi = 0; fi < nf; ++fi) {
+            const int nk = (nkp >> (4 * fi)) & 15;
+            if (nk == 0) continue;
+            f32x4 e[T];
+            const int fk = (funcp >> (4 * fi)) & 15;
+            const float ex = fi == 0 ? ex0 : (fi == 1 ? ex1 : (fi == 2 ? ex2 : ex3));
+#pragma unroll
+            for (int t = 0; t < T; ++t) e[t] = apply_func(fk, ex, z[mt1][t]);
+            gemm_block<MT2, T>(wA2 + (mt1 * nf + fi) * MT2 * 64, e, y, nk);
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT2; ++mt)
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+            if (tile[t] < P.n_tiles) P.out[((size_t)tile[t] * P.nb_out + out_blk + mt) * 64 + lane] = y[mt][t];
+}
+
+
+typedef void (*StageFn)(StageParams);
+typedef void (*StageFn2)(StageParams, StageParams);
+
+// kernels living in the other translation units
+StageFn pick_stage0(int mt1, int mt2, int T, int x_dtype);            // hg_fused_front.hip
+StageFn pick_stage0p(int x_dtype);
+StageFn2 pick_stage01p(int x_dtype, bool stamp);
+StageFn pick_igsfa(int ms, int mo, int T, int kb1);                   // hg_fused_igsfa.hip
+void launch_im2frag(const void* x, int x_dtype, int64_t ldx, int64_t n_rows, int n_tiles, int nb, const int32_t* gcol, f32x4* out,
+                    int vec4, hipStream_t st);
+
+// 4 consecutive input elements -> 4 floats (16-byte / 4-byte / 32-byte loads)
+template <typename XT> struct Vec4Load;
+template <> struct Vec4Load<float> {
+    static __device__ __forceinline__ f32x4 ld(const float* p) { return *(const f32x4*)p; }
+};
+template <> struct Vec4Load<uint8_t> {
+    static __device__ __forceinline__ f32x4 ld(const uint8_t* p) {
+        uint32_t w = *(const uint32_t*)p;
+        f32x4 v;
+        v[0] = (float)(w & 0xff);
+        v[1] = (float)((w >> 8) & 0xff);
+        v[2] = (float)((w >> 16) & 0xff);
+        v[3] = (float)(w >> 24);
+        return v;
+    }
+};
+template <> struct Vec4Load<double> {
+    static __device__ __forceinline__ f32x4 ld(const double* p) {
+        typedef double f64x2 __attribute__((ext_vector_type(2)));
+        f64x2 a = *(const f64x2*)p, b = *(const f64x2*)(p + 2);
+        f32x4 v;
+        v[0] = (float)a[0];
+        v[1] = (float)a[1];
+        v[2] = (float)b[0];
+        v[3] = (float)b[1];
+        return v;
+    }
+};
+
+
+}  // namespace fused
+}  // namespace hg

@@ -1,0 +1,487 @@
+// Fused plan, first-layer kernels: the caller's row-major sub-image matrix -> fragment-order activations
+// (layer 0 alone, its persistent variant, and layers 0+1 in one kernel).  See hg_fused.hip for the data
+// layout and the planner.
+#include "hg_fused_dev.hpp"
+
+namespace hg {
+namespace fused {
+
+// Stage 0: input = caller's row-major sub-image matrix.  The WG stages, for T batch tiles, the
+// column runs its node chunk needs (full 16 B/lane coalesced row segments when alignment allows)
+// into an LDS tile [sub-image][column]; each wave then takes every 4th node of the chunk and
+// reads its receptive field out of LDS (one ds_read_b128 when the four k-steps of a lane are
+// contiguous, e.g. 4-pixel-wide fields), subtracting the node's input mean on the way.
+template <int MT1, int MT2, int T, typename XT>
+__global__ void __launch_bounds__(512) k_stage0(StageParams P) {
+    extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
+    float* lds = (float*)smem;
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nthr >> 6, g = lane >> 4, j = lane & 15;
+    const int ci = blockIdx.x % P.n_chunks, grp = blockIdx.x / P.n_chunks;
+    const DChunk ck = P.chunks[ci];
+    int tile[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) tile[t] = grp * T + t;
+    const XT* x = (const XT*)P.x;
+    const int stride = P.lds_stride;
+    if (P.vec4) {
+        const int pps = ck.n_pieces;             // 16-byte pieces per sub-image
+        const int total = T * 16 * pps;
+        constexpr int NB = 8;                    // loads in flight per thread
+        for (int base = 0; base < total; base += nthr * NB) {
+            f32x4 v[NB];
+            int dsto[NB];
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const int idx = base + k * nthr + tid;
+                dsto[k] = -1;
+                if (idx < total) {
+                    const int sj = idx / pps, pc = idx - sj * pps;
+                    const int2 pcol = P.piece_col[ck.piece_begin + pc];   // {source column, LDS word offset}
+                    const int tl = tile[0] + sj / 16;
+                    const int64_t row = (int64_t)tl * 16 + (sj & 15);
+                    dsto[k] = sj * stride + pcol.y;
+                    if (tl < P.n_tiles && row < P.n_rows)
+                        v[k] = Vec4Load<XT>::ld(x + row * P.ldx + pcol.x);
+                    else
+                        v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NB; ++k)
+                if (dsto[k] >= 0) *(f32x4*)(lds + dsto[k]) = v[k];
+        }
+        if (tid < T * 16) lds[tid * stride + stride - 1] = 0.f;
+    } else {
+        for (int t = 0; t < T; ++t)
+            for (int jj = wave; jj < 16; jj += nw) {
+                const int64_t row = (int64_t)tile[t] * 16 + jj;
+                float* dst = lds + (t * 16 + jj) * stride;
+                const bool ok = tile[t] < P.n_tiles && row < P.n_rows;
+                const XT* src = x + (ok ? row : 0) * P.ldx;
+                for (int ri = 0; ri < ck.run_count; ++ri) {
+                    const DRun rn = P.runs[ck.run_begin + ri];
+                    for (int e = lane; e < rn.len; e += 64) dst[rn.lds_off + e] = ok ? (float)src[rn.start + e] : 0.f;
+                }
+                if (lane == 0) dst[stride - 1] = 0.f;  // the "zero column" padded k positions point at
+            }
+    }
+    __syncthreads();
+    for (int ni = ck.node_begin + wave; ni < ck.node_begin + ck.node_count; ni += nw) {
+        const f32x4* wA1 = P.afrag + (size_t)ni * P.node_blocks * 64 + lane;
+        const f32x4* wA2 = wA1 + P.kb1 * MT1 * 64;
+        const float* b1 = P.bias + (size_t)ni * P.bias_floats;
+        f32x4 z[MT1][T];
+#pragma unroll
+        for (int mt = 0; mt < MT1; ++mt) {
+            f32x4 bb = *(const f32x4*)(b1 + mt * 16 + g * 4);
+#pragma unroll
+            for (int t = 0; t < T; ++t) z[mt][t] = bb;
+        }
+        for (int kbi = 0; kbi < P.kb1; ++kbi) {
+            const size_t ent = ((size_t)ni * P.kb1 + kbi) * 16 + g * 4;
+            const i32x4 off = *(const i32x4*)(P.koff + ent);
+            const f32x4 mu = *(const f32x4*)(P.kmean + ent);
+            f32x4 bf[T];
+            if (P.contig4) {
+#pragma unroll
+                for (int t = 0; t < T; ++t) bf[t] = *(const f32x4*)(lds + (t * 16 + j) * stride + off[0]) - mu;
+            } else {
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const float* base = lds + (t * 16 + j) * stride;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) bf[t][r] = base[off[r]] - mu[r];
+                }
+            }
+            gemm_block<MT1, T>(wA1 + kbi * MT1 * 64, bf, z, kbi == P.kb1 - 1 ? P.nk_last : 4);
+        }
+        node_tail<MT1, MT2, T>(P, wA2, b1 + MT1 * 16, ni * P.mto, z, tile, lane);
+    }
+}
+
+// Stage 0, persistent + software-pipelined variant for small first-layer nodes (one K-block, one
+// tile in and out, <= 2 expansion functions, 16-byte contiguous receptive-field rows): the
+// workgroup owns one node chunk, keeps the weights of its nodes in REGISTERS (2 node slots per
+// wave), and sweeps tile groups part, part + tile_parts, ...  While tile group i is multiplied out
+// of the LDS tile, the row segments of tile group i+1 are already in flight from HBM into registers
+// (8 x 16 B per thread); they are written to LDS after the barrier that ends the compute phase.
+// No load is issued inside the compute phase, so the in-order vmcnt queue never forces the
+// prefetch to land early.
+template <int T, typename XT>
+__global__ void __launch_bounds__(512) k_stage0p(StageParams P) {
+    extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
+    float* lds = (float*)smem;
+    constexpr int NB = 8, NPW = 2;
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, nw = nthr >> 6, g = lane >> 4, j = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ci = blockIdx.x % P.n_chunks, part = blockIdx.x / P.n_chunks;
+    const DChunk ck = P.chunks[ci];
+    const XT* x = (const XT*)P.x;
+    const int stride = P.lds_stride;
+    const int n_groups = (P.n_tiles + T - 1) / T;
+    // --- per-thread staging bookkeeping (the same pieces for every tile group)
+    const int pps = ck.n_pieces, total = T * 16 * pps;
+    int p_col[NB], p_dst[NB];   // source column; (sub-image << 24 | LDS word offset) or -1
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const int idx = k * nthr + tid;
+        p_col[k] = 0;
+        p_dst[k] = -1;
+        if (idx < total) {
+            const int sj = idx / pps, pc = idx - sj * pps;
+            const int2 pcol = P.piece_col[ck.piece_begin + pc];
+            p_col[k] = pcol.x;
+            p_dst[k] = (sj << 24) | (sj * stride + pcol.y);
+        }
+    }
+    // --- weights of this wave's node slots, resident in registers for the whole sweep
+    int w_off[NPW];
+    f32x4 w_mu[NPW], w_a1[NPW], w_a2[NPW][2], w_b1[NPW], w_b2[NPW];
+    bool w_ok[NPW];
+#pragma unroll
+    for (int sl = 0; sl < NPW; ++sl) {
+        const int nl = wave + sl * nw;
+        w_ok[sl] = nl < ck.node_count;
+        const int ni = ck.node_begin + (w_ok[sl] ? nl : 0);
+        const size_t ent = (size_t)ni * 16 + g * 4;       // kb1 == 1
+        w_off[sl] = P.koff[ent];
+        w_mu[sl] = *(const f32x4*)(P.kmean + ent);
+        const f32x4* wp = P.afrag + (size_t)ni * P.node_blocks * 64 + lane;
+        w_a1[sl] = wp[0];
+        w_a2[sl][0] = wp[64];
+        w_a2[sl][1] = P.nf > 1 ? wp[128] : wp[64];
+        const float* bp = P.bias + (size_t)ni * P.bias_floats + g * 4;
+        w_b1[sl] = *(const f32x4*)bp;
+        w_b2[sl] = *(const f32x4*)(bp + 16);
+    }
+    const int nk1 = P.nk_last;
+    const int nk2a = P.nk2p[0] & 15, nk2b = (P.nk2p[0] >> 4) & 15;
+    const int fk0 = P.funcp & 15, fk1 = (P.funcp >> 4) & 15;
+    const float ex0 = P.expo[0], ex1 = P.expo[1];
+
+    auto fetch = [&](int grp, f32x4 (&v)[NB]) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int64_t row = (int64_t)grp * (T * 16) + (p_dst[k] >> 24);
+            if (p_dst[k] >= 0 && row < P.n_rows)
+                v[k] = Vec4Load<XT>::ld(x + row * P.ldx + p_col[k]);
+            else
+                v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    f32x4 v[NB];
+    if (part < n_groups) fetch(part, v);
+    for (int grp = part; grp < n_groups; grp += P.tile_parts) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k)
+            if (p_dst[k] >= 0) *(f32x4*)(lds + (p_dst[k] & 0xffffff)) = v[k];
+        if (tid < T * 16) lds[tid * stride + stride - 1] = 0.f;
+        __syncthreads();
+        if (grp + P.tile_parts < n_groups) fetch(grp + P.tile_parts, v);
+        int tile[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) tile[t] = grp * T + t;
+#pragma unroll
+        for (int sl = 0; sl < NPW; ++sl) {
+            if (!w_ok[sl]) continue;
+            const int ni = ck.node_begin + wave + sl * nw;
+            f32x4 z[1][T], y[1][T], bf[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                bf[t] = *(const f32x4*)(lds + (t * 16 + j) * stride + w_off[sl]) - w_mu[sl];
+                z[0][t] = w_b1[sl];
+                y[0][t] = w_b2[sl];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (r < nk1) {
+#pragma unroll
+                    for (int t = 0; t < T; ++t) z[0][t] = MFMA16(w_a1[sl][r], bf[t][r], z[0][t]);
+                }
+            {
+                f32x4 e[T];
+#pragma unroll
+                for (int t = 0; t < T; ++t) e[t] = apply_func(fk0, ex0, z[0][t]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (r < nk2a) {
+#pragma unroll
+                        for (int t = 0; t < T; ++t) y[0][t] = MFMA16(w_a2[sl][0][r], e[t][r], y[0][t]);
+                    }
+            }
+            if (P.nf > 1) {
+                f32x4 e[T];
+#pragma unroll
+                for (int t = 0; t < T; ++t) e[t] = apply_func(fk1, ex1, z[0][t]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (r < nk2b) {
+#pragma unroll
+                        for (int t = 0; t < T; ++t) y[0][t] = MFMA16(w_a2[sl][1][r], e[t][r], y[0][t]);
+                    }
+            }
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+                if (tile[t] < P.n_tiles) P.out[((size_t)tile[t] * P.nb_out + ni) * 64 + lane] = y[0][t];
+        }
+        __syncthreads();
+    }
+}
+
+// Stages 0 AND 1 in one persistent kernel (the U11L front end): same structure as k_stage0p, but a
+// wave's two node slots are ADJACENT layer-0 nodes 2w, 2w+1 — the two children of layer-1 node w of
+// the chunk — so their output accumulators are, in registers, the two K-blocks of that layer-1
+// node's first affine.  Layer-1 weights (4 + 8 fragment blocks) are register resident too.  The
+// layer-0 activation (64 KiB per sub-image written and read back) never exists in memory.
+// Requirements checked on the host: layer 0 as for k_stage0p; layer-1 node n reads exactly the
+// blocks of layer-0 nodes 2n and 2n+1; both layer-1 affines have <= 32 outputs; same <= 2 functions.
+template <typename XT, bool STAMP = false>
+__global__ void __launch_bounds__(512) k_stage01p(StageParams P, StageParams Q) {
+    extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
+    float* lds = (float*)smem;
+    constexpr int T = 2, NB = 4, NPW = 2;
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, g = lane >> 4, j = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ci = blockIdx.x % P.n_chunks, part = blockIdx.x / P.n_chunks;
+    const DChunk ck = P.chunks[ci];
+    const XT* x = (const XT*)P.x;
+    const int stride = P.lds_stride;
+    const int n_groups = (P.n_tiles + T - 1) / T;
+    const int pps = ck.n_pieces, total = T * 16 * pps;
+    const XT* p_src[NB];   // address of the piece in tile group 0; a group advances every piece by T*16 rows
+    int p_dst[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const int idx = k * nthr + tid;
+        p_src[k] = x;
+        p_dst[k] = -1;
+        if (idx < total) {
+            const int sj = idx / pps, pc = idx - sj * pps;
+            const int2 pcol = P.piece_col[ck.piece_begin + pc];
+            p_src[k] = x + (int64_t)sj * P.ldx + pcol.x;
+            p_dst[k] = (sj << 24) | (sj * stride + pcol.y);
+        }
+    }
+    const int64_t grp_step = (int64_t)(T * 16) * P.ldx;
+    // layer-0 weights of the two slots
+    int w_off[NPW];
+    f32x4 w_mu[NPW], w_a1[NPW], w_a2[NPW][2], w_b1[NPW], w_b2[NPW];
+    const bool w_ok = 2 * wave + 1 < ck.node_count;    // both children present (chunks hold whole pairs)
+#pragma unroll
+    for (int sl = 0; sl < NPW; ++sl) {
+        const int ni = ck.node_begin + (w_ok ? 2 * wave + sl : 0);
+        const size_t ent = (size_t)ni * 16 + g * 4;
+        w_off[sl] = P.koff[ent];
+        w_mu[sl] = *(const f32x4*)(P.kmean + ent);
+        const f32x4* wp = P.afrag + (size_t)ni * P.node_blocks * 64 + lane;
+        w_a1[sl] = wp[0];
+        w_a2[sl][0] = wp[64];
+        w_a2[sl][1] = P.nf > 1 ? wp[128] : wp[64];
+        const float* bp = P.bias + (size_t)ni * P.bias_floats + g * 4;
+        w_b1[sl] = *(const f32x4*)bp;
+        w_b2[sl] = *(const f32x4*)(bp + 16);
+    }
+    // layer-1 node of this wave: A1 [kb 0..1][mt 0..1], A2 [mt1 0..1][fi 0..1][mt2 0..1], biases
+    const int n1 = (ck.node_begin >> 1) + (w_ok ? wave : 0);
+    f32x4 q_a1[2][2], q_a2[2][2][2], q_b1[2], q_b2[2];
+    {
+        const f32x4* wq = Q.afrag + (size_t)n1 * Q.node_blocks * 64 + lane;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) q_a1[kb][mt] = wq[(kb * 2 + mt) * 64];
+        const f32x4* wq2 = wq + Q.kb1 * 2 * 64;
+#pragma unroll
+        for (int m1 = 0; m1 < 2; ++m1)
+#pragma unroll
+            for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) q_a2[m1][fi][mt] = wq2[((m1 * Q.nf + (fi < Q.nf ? fi : 0)) * 2 + mt) * 64];
+        const float* bq = Q.bias + (size_t)n1 * Q.bias_floats + g * 4;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            q_b1[mt] = *(const f32x4*)(bq + mt * 16);
+            q_b2[mt] = *(const f32x4*)(bq + 32 + mt * 16);
+        }
+    }
+    const int fk0 = P.funcp & 15, fk1 = (P.funcp >> 4) & 15;
+    const float ex0 = P.expo[0], ex1 = P.expo[1];
+    const int qfk0 = Q.funcp & 15, qfk1 = (Q.funcp >> 4) & 15;
+    const float qex0 = Q.expo[0], qex1 = Q.expo[1];
+
+    auto fetch = [&](int grp, f32x4 (&v)[NB]) {
+        const int64_t goff = (int64_t)grp * grp_step;            // wave-uniform
+        const int64_t rows_left = P.n_rows - (int64_t)grp * (T * 16);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            if (p_dst[k] >= 0 && (p_dst[k] >> 24) < rows_left)
+                v[k] = Vec4Load<XT>::ld(p_src[k] + goff);
+            else
+                v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    f32x4 v[NB];
+    if (part < n_groups) fetch(part, v);
+    // two LDS tiles, used alternately: one barrier per tile group is enough (a wave that writes tile
+    // i+1 has passed barrier i, i.e. every wave has finished reading tile i-1, which shares its buffer)
+    const int buf_words = T * 16 * stride;
+    float* lds0 = lds;
+    int flip = 0;
+    unsigned long long t_w = 0, t_f = 0, t_l0 = 0, t_l1 = 0, t_all0 = 0, rt0 = 0, ts = 0;
+    int n_it = 0;
+    if (STAMP) {
+        t_all0 = stamp_now();
+        rt0 = __builtin_amdgcn_s_memrealtime();
+    }
+    for (int grp = part; grp < n_groups; grp += P.tile_parts) {
+        if (STAMP) ts = stamp_now();
+        lds = lds0 + flip * buf_words;
+        flip ^= 1;
+#pragma unroll
+        for (int k = 0; k < NB; ++k)
+            if (p_dst[k] >= 0) *(f32x4*)(lds + (p_dst[k] & 0xffffff)) = v[k];
+        if (tid < T * 16) lds[tid * stride + stride - 1] = 0.f;
+        __syncthreads();
+        if (STAMP) { unsigned long long t = stamp_now(); t_w += t - ts; ts = t; }
+        if (grp + P.tile_parts < n_groups) fetch(grp + P.tile_parts, v);
+        if (STAMP) { unsigned long long t = stamp_now(); t_f += t - ts; ts = t; }
+        if (w_ok) {
+            int tile[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) tile[t] = grp * T + t;
+            // ---- layer 0: two children
+            f32x4 y0[NPW][T];
+#pragma unroll
+            for (int sl = 0; sl < NPW; ++sl) {
+                f32x4 z[T], bf[T];
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    bf[t] = *(const f32x4*)(lds + (t * 16 + j) * stride + w_off[sl]) - w_mu[sl];
+                    z[t] = w_b1[sl];
+                    y0[sl][t] = w_b2[sl];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int t = 0; t < T; ++t) z[t] = MFMA16(w_a1[sl][r], bf[t][r], z[t]);
+                {
+                    f32x4 e[T];
+#pragma unroll
+                    for (int t = 0; t < T; ++t) e[t] = apply_func(fk0, ex0, z[t]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int t = 0; t < T; ++t) y0[sl][t] = MFMA16(w_a2[sl][0][r], e[t][r], y0[sl][t]);
+                }
+                {
+                    f32x4 e[T];
+#pragma unroll
+                    for (int t = 0; t < T; ++t) e[t] = apply_func(fk1, ex1, z[t]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int t = 0; t < T; ++t) y0[sl][t] = MFMA16(w_a2[sl][1][r], e[t][r], y0[sl][t]);
+                }
+            }
+            if (STAMP) { unsigned long long t = stamp_now(); t_l0 += t - ts; ts = t; }
+            // ---- layer 1: K-blocks of the first affine are the children's accumulators
+            f32x4 z1[2][T], y1[2][T];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    z1[mt][t] = q_b1[mt];
+                    y1[mt][t] = q_b2[mt];
+                }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int t = 0; t < T; ++t) z1[mt][t] = MFMA16(q_a1[kb][mt][r], y0[kb][t][r], z1[mt][t]);
+#pragma unroll
+            for (int fi = 0; fi < 2; ++fi) {        // z tile 0: full, branch-free
+                f32x4 e[T];
+#pragma unroll
+                for (int t = 0; t < T; ++t) e[t] = apply_func(fi == 0 ? qfk0 : qfk1, fi == 0 ? qex0 : qex1, z1[0][t]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int t = 0; t < T; ++t) y1[mt][t] = MFMA16(q_a2[0][fi][mt][r], e[t][r], y1[mt][t]);
+            }
+#pragma unroll
+            for (int fi = 0; fi < 2; ++fi) {        // z tile 1: partial (runtime k-step count)
+                const int nk = (int)((Q.nk2p[1] >> (4 * fi)) & 15);
+                f32x4 e[T];
+#pragma unroll
+                for (int t = 0; t < T; ++t) e[t] = apply_func(fi == 0 ? qfk0 : qfk1, fi == 0 ? qex0 : qex1, z1[1][t]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (r < nk) {
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                            for (int t = 0; t < T; ++t) y1[mt][t] = MFMA16(q_a2[1][fi][mt][r], e[t][r], y1[mt][t]);
+                    }
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+                    if (tile[t] < P.n_tiles) Q.out[((size_t)tile[t] * Q.nb_out + (size_t)n1 * Q.mto + mt) * 64 + lane] = y1[mt][t];
+            if (STAMP) { unsigned long long t = stamp_now(); t_l1 += t - ts; ts = t; ++n_it; }
+        }
+    }
+    if (STAMP && lane == 0 && P.stamps) {
+        unsigned long long* o = P.stamps + ((size_t)blockIdx.x * 8 + wave) * 8;
+        o[0] = t_w; o[1] = t_f; o[2] = t_l0; o[3] = t_l1;
+        o[4] = stamp_now() - t_all0;
+        o[5] = __builtin_amdgcn_s_memrealtime() - rt0;
+        o[6] = (unsigned long long)n_it;
+    }
+}
+
+template <int MT1, int MT2, typename XT>
+static StageFn pick_stage0_t(int T) {
+    if (T == 4) return k_stage0<MT1, MT2, 4, XT>;
+    return k_stage0<MT1, MT2, 1, XT>;
+}
+template <int MT1, typename XT>
+static StageFn pick_stage0_m2(int mt2, int T) {
+    switch (mt2) {
+        case 1: return pick_stage0_t<MT1, 1, XT>(T);
+        case 2: return pick_stage0_t<MT1, 2, XT>(T);
+        case 3: return pick_stage0_t<MT1, 3, XT>(T);
+        default: return pick_stage0_t<MT1, 4, XT>(T);
+    }
+}
+template <typename XT>
+static StageFn pick_stage0_x(int mt1, int mt2, int T) {
+    switch (mt1) {
+        case 1: return pick_stage0_m2<1, XT>(mt2, T);
+        case 2: return pick_stage0_m2<2, XT>(mt2, T);
+        case 3: return pick_stage0_m2<3, XT>(mt2, T);
+        default: return pick_stage0_m2<4, XT>(mt2, T);
+    }
+}
+StageFn pick_stage0(int mt1, int mt2, int T, int x_dtype) {
+    switch (x_dtype) {
+        case HG_U8: return pick_stage0_x<uint8_t>(mt1, mt2, T);
+        case HG_F32: return pick_stage0_x<float>(mt1, mt2, T);
+        default: return pick_stage0_x<double>(mt1, mt2, T);
+    }
+}
+StageFn pick_stage0p(int x_dtype) {
+    return x_dtype == HG_U8 ? (StageFn)k_stage0p<4, uint8_t> : x_dtype == HG_F32 ? (StageFn)k_stage0p<4, float> : (StageFn)k_stage0p<4, double>;
+}
+StageFn2 pick_stage01p(int x_dtype, bool stamp) {
+    if (stamp && x_dtype == HG_F32) return (StageFn2)k_stage01p<float, true>;
+    return x_dtype == HG_U8 ? (StageFn2)k_stage01p<uint8_t> : x_dtype == HG_F32 ? (StageFn2)k_stage01p<float> : (StageFn2)k_stage01p<double>;
+}
+
+}  // namespace fused
+}  // namespace hg

@@ -1,0 +1,202 @@
+// Fused plan, iGSFA layers: gather pre-pass and the three-GEMM node kernel.
+#include "hg_fused_dev.hpp"
+
+namespace hg {
+namespace fused {
+
+// Row-major input -> fragment order (used in front of a first layer of iGSFA nodes, whose kernel
+// reads fragment-order blocks like every later layer).  One wave per (batch tile, block): lane (g, j)
+// gathers the four columns of its four k-steps for sub-image j.
+template <typename XT>
+__global__ void __launch_bounds__(256) k_im2frag(const XT* __restrict__ x, int64_t ldx, int64_t n_rows, int n_tiles, int nb,
+                                                 const int32_t* __restrict__ gcol, f32x4* __restrict__ out, int vec4) {
+    const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+    const int64_t wid = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (wid >= (int64_t)n_tiles * nb) return;
+    const int tile = (int)(wid / nb), blk = (int)(wid - (int64_t)tile * nb);
+    const int64_t row = (int64_t)tile * 16 + j;
+    const i32x4 c = *(const i32x4*)(gcol + (size_t)blk * 16 + g * 4);
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (row < n_rows) {
+        const XT* xr = x + row * ldx;
+        if (vec4 && c[0] >= 0 && c[3] == c[0] + 3) {     // four contiguous, 16-byte aligned columns
+            v = Vec4Load<XT>::ld(xr + c[0]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (c[r] >= 0) v[r] = (float)xr[c[r]];
+        }
+    }
+    out[(size_t)wid * 64 + lane] = v;
+}
+
+// A layer of iGSFA nodes.  Same workgroup structure as k_stage (node
+// weights once into LDS, persistent sweep over tile groups), three chained GEMMs per node, all
+// operands in registers:
+//   x0[kb] = input fragments - mean                                   (K-blocks of the node input)
+//   y[ms] += W1[fi][kb][ms] * f_fi(x0[kb])          s = scaled slow features (rows of y tiles < MS)
+//   x0[kb] = x0[kb] + bias_r[kb] + W2[kb][ms] * y[ms]                 r = x0 - lr(s): the input fragment
+//                                                                     IS the C operand (same layout)
+//   y[mo] += W3[kb][mo] * x0[kb]                    q = pca(r) lands in the remaining rows of y
+// Output tiles hold [s, q] in the caller's column order.
+template <int MS, int MO, int T, int KBM>   // KBM: K-block capacity of a node input (2 or 8; <= 128 inputs)
+__global__ void __launch_bounds__(512, (KBM <= 2 ? 4 : 2)) k_igsfa(StageParams P) {
+    extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, nw = nthr >> 6, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // a workgroup owns a group of `nodes_per_group` consecutive nodes (their weights fit LDS together)
+    const int npg = P.nodes_per_group;
+    const int grp_id = blockIdx.x % P.n_chunks, part = blockIdx.x / P.n_chunks;
+    const int g0 = grp_id * npg, gn = min(npg, P.n_nodes - g0);
+    float* sb = (float*)(smem + (size_t)npg * P.node_blocks * 64);
+    int2* stab = (int2*)(sb + npg * P.bias_floats);
+    {
+        const f32x4* src = P.afrag + (size_t)g0 * P.node_blocks * 64;
+        const int nvec = gn * P.node_blocks * 64;
+        int i = tid;
+        for (; i + 3 * nthr < nvec; i += 4 * nthr) {
+            f32x4 v0 = src[i], v1 = src[i + nthr], v2 = src[i + 2 * nthr], v3 = src[i + 3 * nthr];
+            smem[i] = v0;
+            smem[i + nthr] = v1;
+            smem[i + 2 * nthr] = v2;
+            smem[i + 3 * nthr] = v3;
+        }
+        for (; i < nvec; i += nthr) smem[i] = src[i];
+        const float* bsrc = P.bias + (size_t)g0 * P.bias_floats;
+        for (int k = tid; k < gn * P.bias_floats; k += nthr) sb[k] = bsrc[k];
+        const int2* tsrc = P.kb1tab + (size_t)g0 * P.kb1;
+        for (int k = tid; k < gn * P.kb1; k += nthr) stab[k] = tsrc[k];
+    }
+    __syncthreads();
+    const int kb1 = P.kb1, nf = P.nf;
+    for (int grp = part; grp < P.tile_groups; grp += P.tile_parts) {
+        int tile[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) tile[t] = (grp * nw + wave) * T + t;
+        if (tile[0] >= P.n_tiles) break;
+      for (int ln = 0; ln < gn; ++ln) {
+        const int node = g0 + ln;
+        const f32x4* w1 = smem + (size_t)ln * P.node_blocks * 64 + lane;   // [fi][kb][ms]
+        const f32x4* w2 = w1 + (size_t)nf * kb1 * MS * 64;              // [kb][ms]
+        const f32x4* w3 = w2 + (size_t)kb1 * MS * 64;                   // [kb][mo]
+        const float* by = sb + ln * P.bias_floats;                      // [MO][16]
+        const float* br = by + MO * 16;                                 // [kb][16]
+        const float* mu = br + kb1 * 16;                                // [kb][16]
+        const int2* ktab = stab + ln * kb1;
+        f32x4 x0[KBM][T];
+        int nk1[KBM];
+#pragma unroll
+        for (int kb = 0; kb < KBM; ++kb) {
+            nk1[kb] = 0;
+            if (kb < kb1) {
+                const int2 e = ktab[kb];
+                const int sbk = __builtin_amdgcn_readfirstlane(e.x);
+                nk1[kb] = __builtin_amdgcn_readfirstlane(e.y);
+                const f32x4 m = *(const f32x4*)(mu + kb * 16 + g * 4);
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const int tl = tile[t] < P.n_tiles ? tile[t] : tile[0];
+                    x0[kb][t] = P.in[((size_t)tl * P.nb_in + sbk) * 64 + lane] - m;
+                }
+            }
+        }
+        f32x4 y[MO][T];
+#pragma unroll
+        for (int mo = 0; mo < MO; ++mo) {
+            const f32x4 bb = *(const f32x4*)(by + mo * 16 + g * 4);
+#pragma unroll
+            for (int t = 0; t < T; ++t) y[mo][t] = bb;
+        }
+        // G1: slow features from the expanded input
+        for (int fi = 0; fi < nf; ++fi) {
+            const int fk = (P.funcp >> (4 * fi)) & 15;
+            const float ex = P.expo[fi];
+#pragma unroll
+            for (int kb = 0; kb < KBM; ++kb) {
+                if (kb >= kb1) continue;
+                f32x4 e[T];
+#pragma unroll
+                for (int t = 0; t < T; ++t) e[t] = apply_func(fk, ex, x0[kb][t]);
+                const f32x4* wp = w1 + ((size_t)(fi * kb1 + kb) * MS) * 64;
+#pragma unroll
+                for (int ms = 0; ms < MS; ++ms) {      // only the tiles that hold slow features
+                    const f32x4 a = wp[ms * 64];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (r < nk1[kb]) {
+#pragma unroll
+                            for (int t = 0; t < T; ++t) y[ms][t] = MFMA16(a[r], e[t][r], y[ms][t]);
+                        }
+                }
+            }
+        }
+        // G2: residual r = x0 - lr(s), accumulated into the input fragments
+        if (P.ig_has_lr) {
+#pragma unroll
+            for (int kb = 0; kb < KBM; ++kb) {
+                if (kb >= kb1) continue;
+                const f32x4 bb = *(const f32x4*)(br + kb * 16 + g * 4);
+#pragma unroll
+                for (int t = 0; t < T; ++t) x0[kb][t] += bb;
+#pragma unroll
+                for (int ms = 0; ms < MS; ++ms) {
+                    const f32x4 a = w2[((size_t)kb * MS + ms) * 64];
+                    const int nks = (P.nk2p[0] >> (4 * ms)) & 15;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (r < nks) {
+#pragma unroll
+                            for (int t = 0; t < T; ++t) x0[kb][t] = MFMA16(a[r], y[ms][t][r], x0[kb][t]);
+                        }
+                }
+            }
+        }
+        // G3: q = pca(r) into the remaining rows of the output tiles
+#pragma unroll
+        for (int kb = 0; kb < KBM; ++kb) {
+            if (kb >= kb1) continue;
+            gemm_block<MO, T>(w3 + ((size_t)kb * MO) * 64, x0[kb], y, nk1[kb]);
+        }
+#pragma unroll
+        for (int mo = 0; mo < MO; ++mo)
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+                if (tile[t] < P.n_tiles) P.out[((size_t)tile[t] * P.nb_out + (size_t)node * MO + mo) * 64 + lane] = y[mo][t];
+      }
+    }
+}
+
+template <int MS, int MO>
+static StageFn pick_igsfa_t(int T, int kb1) {
+    if (kb1 <= 2) return T == 2 ? (StageFn)k_igsfa<MS, MO, 2, 2> : (StageFn)k_igsfa<MS, MO, 1, 2>;
+    return T == 2 ? (StageFn)k_igsfa<MS, MO, 2, 8> : (StageFn)k_igsfa<MS, MO, 1, 8>;
+}
+StageFn pick_igsfa(int ms, int mo, int T, int kb1) {   // ms <= mo (the slow features are a prefix of the output)
+    switch (ms * 10 + mo) {
+        case 11: return pick_igsfa_t<1, 1>(T, kb1);
+        case 12: return pick_igsfa_t<1, 2>(T, kb1);
+        case 13: return pick_igsfa_t<1, 3>(T, kb1);
+        case 14: return pick_igsfa_t<1, 4>(T, kb1);
+        case 22: return pick_igsfa_t<2, 2>(T, kb1);
+        case 23: return pick_igsfa_t<2, 3>(T, kb1);
+        case 24: return pick_igsfa_t<2, 4>(T, kb1);
+        case 33: return pick_igsfa_t<3, 3>(T, kb1);
+        case 34: return pick_igsfa_t<3, 4>(T, kb1);
+        default: return pick_igsfa_t<4, 4>(T, kb1);
+    }
+}
+
+void launch_im2frag(const void* x, int x_dtype, int64_t ldx, int64_t n_rows, int n_tiles, int nb, const int32_t* gcol, f32x4* out,
+                    int vec4, hipStream_t st) {
+    const int64_t waves = (int64_t)n_tiles * nb;
+    const unsigned grid = (unsigned)((waves + 3) / 4);
+    if (x_dtype == HG_U8)
+        hipLaunchKernelGGL(k_im2frag<uint8_t>, grid, 256, 0, st, (const uint8_t*)x, ldx, n_rows, n_tiles, nb, gcol, out, vec4);
+    else if (x_dtype == HG_F32)
+        hipLaunchKernelGGL(k_im2frag<float>, grid, 256, 0, st, (const float*)x, ldx, n_rows, n_tiles, nb, gcol, out, vec4);
+    else
+        hipLaunchKernelGGL(k_im2frag<double>, grid, 256, 0, st, (const double*)x, ldx, n_rows, n_tiles, nb, gcol, out, vec4);
+}
+
+}  // namespace fused
+}  // namespace hg
