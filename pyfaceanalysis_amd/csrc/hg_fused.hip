@@ -1066,9 +1066,9 @@ public:
                 size_t lds_bytes = (size_t)npg * s.node_blocks * 1024 + (size_t)npg * s.bias_floats * 4 + (size_t)npg * s.kb1 * 8;
                 StageFn fn = pick_stage(s.mt1, s.mt2, T);
                 const char* stamp_env = getenv("HIGSFA_STAMP");
-                if (stamp_env && atoi(stamp_env) == (int)si && s.mt1 == 4 && s.mt2 == 4 && T == 2) {
+                if (stamp_env && atoi(stamp_env) == (int)si && s.mt1 == s.mt2 && (s.mt1 == 4 || s.mt1 == 3) && T == 2) {
                     // diagnostic instantiation with s_memtime stamps (never used in timed runs)
-                    fn = k_stage<4, 4, 2, true>;
+                    fn = s.mt1 == 4 ? (StageFn)k_stage<4, 4, 2, true> : (StageFn)k_stage<3, 3, 2, true>;
                     stamp_buf_.alloc((size_t)blocks * 8 * 6 * 8);
                     HG_HIP(hipMemsetAsync(stamp_buf_.p, 0, stamp_buf_.bytes, st));
                     P.stamps = (unsigned long long*)stamp_buf_.p;
