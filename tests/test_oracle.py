@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from oracle import mdp_restate as oracle
-from oracle import ref_c
+from oracle import fast_cpu, ref_c
 from pyfaceanalysis_amd import nodes as N
 from pyfaceanalysis_amd import synth
 from pyfaceanalysis_amd.blob import blob_to_flow
@@ -24,6 +24,29 @@ def test_golden_flows(path):
     assert np.abs(y - g["y"]).max() <= 1e-11 * np.abs(g["y"]).max()
     yc = ref_c.execute_flow(nodes, g["x"])
     assert np.abs(yc - g["y"]).max() <= 1e-11 * np.abs(g["y"]).max()
+
+
+def test_fast_cpu_timing_leg_agrees():
+    """oracle/fast_cpu (bench.py's "good CPU" timing point) computes the same flow: golden nets it covers
+    to 1e-11, ragged row counts, 1 and 3 threads; node kinds it does not cover raise."""
+    covered = 0
+    for path in sorted(glob.glob(os.path.join(GOLD, "flow_*.npz"))):
+        g = np.load(path)
+        nodes = blob_to_flow(g["blob"].tobytes())
+        try:
+            plan = fast_cpu.Plan(nodes)
+        except TypeError:
+            continue
+        covered += 1
+        for threads in (1, 3):
+            y = plan.run(g["x"], threads)
+            assert np.abs(y - g["y"]).max() <= 1e-11 * np.abs(g["y"]).max()
+        x = np.tile(g["x"], (5, 1))[:g["x"].shape[0] * 4 + 3]
+        assert np.abs(plan.run(x, 2) - oracle.execute_flow(nodes, x)).max() <= 1e-11 * np.abs(g["y"]).max()
+        assert plan.run(x[:0], 2).shape == (0, nodes[-1].output_dim)
+    assert covered >= 1
+    with pytest.raises(TypeError):
+        fast_cpu.Plan(helpers.product_net(3))
 
 
 @pytest.mark.parametrize("maker", [helpers.overlapping_net, helpers.linear_net, helpers.product_net])
