@@ -296,16 +296,17 @@ __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
         unsigned long long tc0 = 0;
         if (STAMP) tc0 = stamp_now();
         __syncthreads();
-        {   // cooperative copy of the group's weights, 4 x 16 B in flight per thread
+        {   // cooperative copy of the group's weights, 8 x 16 B in flight per thread (an L2 round trip is
+            // ~2k cycles here: the bytes in flight per CU set the copy rate)
             const f32x4* src = P.afrag + (size_t)g0 * P.node_blocks * 64;
             const int nvec = gn * P.node_blocks * 64;
             int i = tid;
-            for (; i + 3 * nthr < nvec; i += 4 * nthr) {
-                f32x4 v0 = src[i], v1 = src[i + nthr], v2 = src[i + 2 * nthr], v3 = src[i + 3 * nthr];
-                smem[i] = v0;
-                smem[i + nthr] = v1;
-                smem[i + 2 * nthr] = v2;
-                smem[i + 3 * nthr] = v3;
+            for (; i + 7 * nthr < nvec; i += 8 * nthr) {
+                f32x4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = src[i + u * nthr];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) smem[i + u * nthr] = v[u];
             }
             for (; i < nvec; i += nthr) smem[i] = src[i];
             const float* bsrc = P.bias + (size_t)g0 * P.bias_floats;
