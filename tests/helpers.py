@@ -69,3 +69,57 @@ def wide_merge_net(seed=0):
     ex = N.GeneralExpansionNode([N.identity, N.unsigned_08expo], 50)
     l1 = N.Layer([N.FlowNode([rand_pca(rng, 520, 50), ex, rand_sfa(rng, 100, 40)])])
     return [l0, l1]
+
+
+def fuzz_net(seed):
+    """Random hierarchy for planner / kernel fuzzing: random grid, field sizes, overlaps, merge directions,
+    uneven per-node widths, random element-wise expansions (incl. sel_exp and odd exponents), optional
+    linear layers and clone layers.  Everything the fused plan claims to cover, nothing it does not."""
+    rng = np.random.default_rng(1000 + seed)
+    w, h = (int(v) for v in rng.choice([6, 8, 12, 16], 2))
+    pool = [N.identity, N.unsigned_08expo, N.signed_08expo, N.unsigned_expo(float(rng.uniform(0.5, 1.5))),
+            N.signed_expo(float(rng.uniform(0.6, 1.2)))]
+    flow, c = [], 1
+    for depth in range(int(rng.integers(1, 5))):
+        if depth == 0:
+            fx, fy = (int(v) for v in rng.choice([2, 3, 4], 2))
+        else:
+            fx, fy = [(2, 1), (1, 2), (2, 2)][int(rng.integers(0, 3))]
+        fx, fy = min(fx, w), min(fy, h)
+        sx = fx if rng.random() < 0.7 or fx == 1 else fx - 1
+        sy = fy if rng.random() < 0.7 or fy == 1 else fy - 1
+        while (w - fx) % sx:
+            sx -= 1
+        while (h - fy) % sy:
+            sy -= 1
+        sb = N.Rectangular2dSwitchboard((w, h), (fx, fy), (sx, sy), c)
+        n_nodes, d_in = sb.output_channels, sb.out_channel_dim
+        uneven = rng.random() < 0.4
+        clone = not uneven and rng.random() < 0.2
+        linear = rng.random() < 0.15
+        p0, s0 = int(rng.integers(2, min(d_in, 40) + 1)), int(rng.integers(2, 50))
+        nf = int(rng.integers(1, 4))
+        funcs = [pool[int(i)] for i in rng.choice(len(pool), nf, replace=False)]
+        if rng.random() < 0.3 and p0 > 4:      # one expansion per layer, like the reference's networks
+            funcs[-1] = N.sel_exp(int(rng.integers(1, p0 - 2)), funcs[-1])
+
+        def make(k):
+            p = max(2, p0 - (k % 3)) if uneven else p0
+            if linear:
+                return N.FlowNode([rand_pca(rng, d_in, p), rand_sfa(rng, p, s0)])
+            ex = N.GeneralExpansionNode(funcs, p)
+            return N.FlowNode([rand_pca(rng, d_in, p, N.WhiteningNode if rng.random() < 0.5 else N.PCANode), ex,
+                               rand_sfa(rng, ex.output_dim, s0, N.GSFANode if rng.random() < 0.5 else N.SFANode)])
+
+        layer = N.CloneLayer(make(0), n_nodes) if clone else N.Layer([make(k) for k in range(n_nodes)])
+        if not clone and len({n.output_dim for n in layer.nodes}) > 1:
+            # the next rectangular switchboard needs one channel width: even the layer out with a head per node
+            m = min(n.output_dim for n in layer.nodes)
+            layer = N.Layer([N.FlowNode(list(n.flow) + [N.HeadNode(n.output_dim, m)]) if n.output_dim > m else n
+                             for n in layer.nodes])
+        flow += [sb, layer]
+        w, h = sb.out_channels_xy
+        c = layer.output_dim // n_nodes
+        if w * h == 1:
+            break
+    return flow

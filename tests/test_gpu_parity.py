@@ -62,6 +62,24 @@ def test_awkward_structures(native_lib, maker, force_generic):
     flow.close()
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzzed_hierarchies(native_lib, seed):
+    """Random hierarchies (helpers.fuzz_net): random grids, overlaps, merge directions, uneven widths, clone and
+    linear layers, odd exponents, sel_exp — fused plan and generic plan against the oracle, ragged batch sizes."""
+    nodes = helpers.fuzz_net(seed)
+    n = [1, 15, 16, 17, 33, 100][seed % 6]
+    x = np.random.default_rng(seed).normal(size=(n, nodes[0].input_dim)) * 1.5
+    ref = oracle.execute_flow(nodes, x)
+    flow = Flow(nodes)
+    assert flow.info().plan_kind == _capi.HG_PLAN_FUSED
+    assert rel_err(flow.execute(x), ref) <= TOL
+    flow.close()
+    if seed % 4 == 0:
+        flow = Flow(nodes, force_generic=True)
+        assert rel_err(flow.execute(x), ref) <= TOL
+        flow.close()
+
+
 @pytest.mark.parametrize("force_generic", [True, False])
 def test_u11l_128_matches_oracle(native_lib, nets, force_generic):
     """BASELINE.json configs[0]: the 11-layer net on 256 sub-images of 128x128."""

@@ -147,3 +147,14 @@ def test_classifier_known_answers():
         prob = p * (2 * np.pi) ** (-d / 2.0) / sd * np.exp(expo - expo.max(axis=1, keepdims=True))
         prob /= prob.sum(axis=1, keepdims=True)
         assert np.allclose(prob @ avg, reg, rtol=1e-10)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzzed_hierarchies_host_side(seed):
+    """helpers.fuzz_net: numpy and C restatements agree, the blob round-trips bit-exactly."""
+    from pyfaceanalysis_amd.blob import flow_to_blob
+    nodes = helpers.fuzz_net(seed)
+    x = np.random.default_rng(seed).normal(size=(9, nodes[0].input_dim)) * 1.5
+    a = oracle.execute_flow(nodes, x)
+    assert np.abs(a - ref_c.execute_flow(nodes, x)).max() <= 1e-12 * np.abs(a).max()
+    assert np.array_equal(a, oracle.execute_flow(blob_to_flow(flow_to_blob(nodes)), x))
