@@ -948,8 +948,9 @@ public:
                     // layers 0 and 1 in one persistent kernel; layer 1 writes where its own launch would
                     StageParams Q = base_params(stages_[1], nullptr, cur);
                     StageFn2 fn = pick_stage01p(x_dtype, false);
-                    const size_t lds2 = (size_t)2 * 2 * 16 * s.lds_stride * 4;   // two tiles of T = 2 batch tiles
                     const int thr01 = 64 * std::max(1, (s.max_chunk_nodes + 1) / 2);   // one wave per pair of layer-0 nodes
+                    // two tiles of T = 2 batch tiles + 10 vectors of 16 floats (means, biases) per wave
+                    const size_t lds2 = (size_t)(kDoubleBuffer01 ? 2 : 1) * 2 * 16 * s.lds_stride * 4 + (size_t)(thr01 / 64) * 160 * 4;
                     const int groups2 = (n_tiles + 1) / 2;
                     int occ = 1;
                     {
@@ -965,6 +966,7 @@ public:
                         }
                     }
                     P.tile_parts = std::max(1, std::min(groups2, 256 * occ / std::max(1, P.n_chunks)));
+                    if (getenv("HIGSFA_DEBUG")) fprintf(stderr, "[front] occ %d threads %d lds %zu chunks %d tile_parts %d\n", occ, thr01, lds2, P.n_chunks, P.tile_parts);
                     const char* stamp_env = getenv("HIGSFA_STAMP");
                     if (stamp_env && atoi(stamp_env) == 0 && x_dtype == HG_F32) {
                         fn = pick_stage01p(HG_F32, true);

@@ -26,6 +26,10 @@ struct DRun {
     int32_t start, len, lds_off, pad;
 };
 
+// k_stage01p: two LDS tiles (one barrier per tile group, 2 workgroups per CU) or one (two barriers, but a
+// third workgroup per CU fits in LDS)
+constexpr bool kDoubleBuffer01 = false;
+
 struct StageParams {
     const f32x4* afrag;   // [node][ A1: kb1 x MT1 | A2: MT1 x nf x MT2 ] blocks of 64 x f32x4
     const float* bias;    // [node][ (MT1 + MT2) x 16 ]

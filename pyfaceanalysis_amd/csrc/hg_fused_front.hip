@@ -236,7 +236,7 @@ __global__ void __launch_bounds__(512) k_stage0p(StageParams P) {
 // Requirements checked on the host: layer 0 as for k_stage0p; layer-1 node n reads exactly the
 // blocks of layer-0 nodes 2n and 2n+1; both layer-1 affines have <= 32 outputs; same <= 2 functions.
 template <typename XT, bool STAMP = false>
-__global__ void __launch_bounds__(512) k_stage01p(StageParams P, StageParams Q) {
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 3))) k_stage01p(StageParams P, StageParams Q) {
     extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
     float* lds = (float*)smem;
     constexpr int T = 2, NB = 4, NPW = 2;
@@ -264,26 +264,33 @@ __global__ void __launch_bounds__(512) k_stage01p(StageParams P, StageParams Q) 
     }
     const int64_t grp_step = (int64_t)(T * 16) * P.ldx;
     // layer-0 weights of the two slots
+    // Means and biases (10 vectors of 16 floats per wave; a lane needs the four of its group g) live in
+    // LDS behind the two tiles and are re-read every tile group: 40 VGPRs less, which is what lets a
+    // third wave per SIMD fit (168 VGPRs) — the weights proper stay in registers.
+    float* cst = lds + (kDoubleBuffer01 ? 2 : 1) * (T * 16 * stride) + wave * 160;
+    enum { C_MU = 0, C_B1 = 2, C_B2 = 4, C_QB1 = 6, C_QB2 = 8 };
     int w_off[NPW];
-    f32x4 w_mu[NPW], w_a1[NPW], w_a2[NPW][2], w_b1[NPW], w_b2[NPW];
+    f32x4 w_a1[NPW], w_a2[NPW][2];
     const bool w_ok = 2 * wave + 1 < ck.node_count;    // both children present (chunks hold whole pairs)
 #pragma unroll
     for (int sl = 0; sl < NPW; ++sl) {
         const int ni = ck.node_begin + (w_ok ? 2 * wave + sl : 0);
         const size_t ent = (size_t)ni * 16 + g * 4;
         w_off[sl] = P.koff[ent];
-        w_mu[sl] = *(const f32x4*)(P.kmean + ent);
+        if (j == 0) *(f32x4*)(cst + (C_MU + sl) * 16 + g * 4) = *(const f32x4*)(P.kmean + ent);
         const f32x4* wp = P.afrag + (size_t)ni * P.node_blocks * 64 + lane;
         w_a1[sl] = wp[0];
         w_a2[sl][0] = wp[64];
         w_a2[sl][1] = P.nf > 1 ? wp[128] : wp[64];
         const float* bp = P.bias + (size_t)ni * P.bias_floats + g * 4;
-        w_b1[sl] = *(const f32x4*)bp;
-        w_b2[sl] = *(const f32x4*)(bp + 16);
+        if (j == 0) {
+            *(f32x4*)(cst + (C_B1 + sl) * 16 + g * 4) = *(const f32x4*)bp;
+            *(f32x4*)(cst + (C_B2 + sl) * 16 + g * 4) = *(const f32x4*)(bp + 16);
+        }
     }
     // layer-1 node of this wave: A1 [kb 0..1][mt 0..1], A2 [mt1 0..1][fi 0..1][mt2 0..1], biases
     const int n1 = (ck.node_begin >> 1) + (w_ok ? wave : 0);
-    f32x4 q_a1[2][2], q_a2[2][2][2], q_b1[2], q_b2[2];
+    f32x4 q_a1[2][2], q_a2[2][2][2];
     {
         const f32x4* wq = Q.afrag + (size_t)n1 * Q.node_blocks * 64 + lane;
 #pragma unroll
@@ -299,10 +306,11 @@ __global__ void __launch_bounds__(512) k_stage01p(StageParams P, StageParams Q) 
                 for (int mt = 0; mt < 2; ++mt) q_a2[m1][fi][mt] = wq2[((m1 * Q.nf + (fi < Q.nf ? fi : 0)) * 2 + mt) * 64];
         const float* bq = Q.bias + (size_t)n1 * Q.bias_floats + g * 4;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            q_b1[mt] = *(const f32x4*)(bq + mt * 16);
-            q_b2[mt] = *(const f32x4*)(bq + 32 + mt * 16);
-        }
+        for (int mt = 0; mt < 2; ++mt)
+            if (j == 0) {
+                *(f32x4*)(cst + (C_QB1 + mt) * 16 + g * 4) = *(const f32x4*)(bq + mt * 16);
+                *(f32x4*)(cst + (C_QB2 + mt) * 16 + g * 4) = *(const f32x4*)(bq + 32 + mt * 16);
+            }
     }
     const int fk0 = P.funcp & 15, fk1 = (P.funcp >> 4) & 15;
     const float ex0 = P.expo[0], ex1 = P.expo[1];
@@ -335,8 +343,12 @@ __global__ void __launch_bounds__(512) k_stage01p(StageParams P, StageParams Q) 
     }
     for (int grp = part; grp < n_groups; grp += P.tile_parts) {
         if (STAMP) ts = stamp_now();
-        lds = lds0 + flip * buf_words;
-        flip ^= 1;
+        if (kDoubleBuffer01) {
+            lds = lds0 + flip * buf_words;
+            flip ^= 1;
+        } else {
+            __syncthreads();   // single tile: every wave is done with the previous tile group
+        }
 #pragma unroll
         for (int k = 0; k < NB; ++k)
             if (p_dst[k] >= 0) *(f32x4*)(lds + (p_dst[k] & 0xffffff)) = v[k];
@@ -354,11 +366,13 @@ __global__ void __launch_bounds__(512) k_stage01p(StageParams P, StageParams Q) 
 #pragma unroll
             for (int sl = 0; sl < NPW; ++sl) {
                 f32x4 z[T], bf[T];
+                const f32x4 mu = *(const f32x4*)(cst + (C_MU + sl) * 16 + g * 4);
+                const f32x4 cb1 = *(const f32x4*)(cst + (C_B1 + sl) * 16 + g * 4), cb2 = *(const f32x4*)(cst + (C_B2 + sl) * 16 + g * 4);
 #pragma unroll
                 for (int t = 0; t < T; ++t) {
-                    bf[t] = *(const f32x4*)(lds + (t * 16 + j) * stride + w_off[sl]) - w_mu[sl];
-                    z[t] = w_b1[sl];
-                    y0[sl][t] = w_b2[sl];
+                    bf[t] = *(const f32x4*)(lds + (t * 16 + j) * stride + w_off[sl]) - mu;
+                    z[t] = cb1;
+                    y0[sl][t] = cb2;
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
@@ -390,8 +404,8 @@ __global__ void __launch_bounds__(512) k_stage01p(StageParams P, StageParams Q) 
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int t = 0; t < T; ++t) {
-                    z1[mt][t] = q_b1[mt];
-                    y1[mt][t] = q_b2[mt];
+                    z1[mt][t] = *(const f32x4*)(cst + (C_QB1 + mt) * 16 + g * 4);
+                    y1[mt][t] = *(const f32x4*)(cst + (C_QB2 + mt) * 16 + g * 4);
                 }
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
