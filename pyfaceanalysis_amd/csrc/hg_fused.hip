@@ -906,13 +906,24 @@ public:
                 continue;
             }
             if (s.kind == 2) {        // iGSFA layer
-                int nw = 8, T = 2;
-                while (nw > 1 && nw * T > n_tiles) nw >>= 1;
-                if (nw * T > n_tiles) T = 1;
+                // waves x tiles per workgroup: the largest shape that still gives every CU a workgroup
+                // (the top layers have 16 .. 1 nodes: with 8 x 2 a single node would run on 16 CUs)
+                static const int ig_shapes[][2] = {{8, 2}, {4, 2}, {4, 1}, {2, 1}, {1, 1}};
+                int nwt = 1, T = 1;     // waves that take tiles x tiles per wave
+                for (auto& sh : ig_shapes) {
+                    const int64_t tg = (n_tiles + sh[0] * sh[1] - 1) / (sh[0] * sh[1]);
+                    if (sh[0] * sh[1] <= std::max(n_tiles, 1) && tg * s.n_nodes >= 256) {
+                        nwt = sh[0];
+                        T = sh[1];
+                        break;
+                    }
+                }
+                const int nw = std::max(nwt, 4);   // never fewer than 4 waves to copy a node's weights
+                P.nodes_per_wg = nwt;
                 P.ig_has_lr = s.ig_has_lr ? 1 : 0;
                 P.nk2p[0] = 0;
                 for (int ms = 0; ms < s.mt1; ++ms) P.nk2p[0] |= (uint32_t)s.ig_nks[ms] << (4 * ms);
-                P.tile_groups = (n_tiles + nw * T - 1) / (nw * T);
+                P.tile_groups = (n_tiles + nwt * T - 1) / (nwt * T);
                 const int npg = 1;   // one node per workgroup measured fastest (236/180 us vs 246-288/220-269 us with 32-96 KiB groups on the 11-layer net)
                 P.nodes_per_group = npg;
                 P.n_chunks = (s.n_nodes + npg - 1) / npg;

@@ -38,7 +38,7 @@ struct StageParams {
     f32x4* out;
     int32_t n_nodes, kb1, nf, has_exp;
     int32_t node_blocks, bias_floats, n_tiles, nb_in, nb_out, mto;
-    int32_t nodes_per_group, nodes_per_wg, n_chunks, tile_groups, tile_parts;
+    int32_t nodes_per_group, nodes_per_wg, n_chunks, tile_groups, tile_parts;   // k_igsfa: nodes_per_wg = waves of a workgroup that take batch tiles
     uint32_t nk2p[kMaxMT];     // per z tile: 4 bits of k-steps per expansion function
     uint32_t funcp;            // 4 bits of ExpKind per expansion function
     float expo[kMaxFuncs];

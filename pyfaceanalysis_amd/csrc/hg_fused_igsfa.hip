@@ -54,12 +54,12 @@ __global__ void __launch_bounds__(512, (KBM <= 2 ? 4 : 2)) k_igsfa(StageParams P
         const f32x4* src = P.afrag + (size_t)g0 * P.node_blocks * 64;
         const int nvec = gn * P.node_blocks * 64;
         int i = tid;
-        for (; i + 3 * nthr < nvec; i += 4 * nthr) {
-            f32x4 v0 = src[i], v1 = src[i + nthr], v2 = src[i + 2 * nthr], v3 = src[i + 3 * nthr];
-            smem[i] = v0;
-            smem[i + nthr] = v1;
-            smem[i + 2 * nthr] = v2;
-            smem[i + 3 * nthr] = v3;
+        for (; i + 7 * nthr < nvec; i += 8 * nthr) {     // 8 x 16 B in flight per thread
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[i + u * nthr];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) smem[i + u * nthr] = v[u];
         }
         for (; i < nvec; i += nthr) smem[i] = src[i];
         const float* bsrc = P.bias + (size_t)g0 * P.bias_floats;
@@ -69,11 +69,14 @@ __global__ void __launch_bounds__(512, (KBM <= 2 ? 4 : 2)) k_igsfa(StageParams P
     }
     __syncthreads();
     const int kb1 = P.kb1, nf = P.nf;
+    // all nw waves copy; only the first nwt take batch tiles (layers of a few nodes: more, smaller
+    // workgroups fill the chip, and a lone wave would copy its node's weights at a crawl)
+    const int nwt = P.nodes_per_wg > 0 ? min(P.nodes_per_wg, nw) : nw;
     for (int grp = part; grp < P.tile_groups; grp += P.tile_parts) {
         int tile[T];
 #pragma unroll
-        for (int t = 0; t < T; ++t) tile[t] = (grp * nw + wave) * T + t;
-        if (tile[0] >= P.n_tiles) break;
+        for (int t = 0; t < T; ++t) tile[t] = (grp * nwt + wave) * T + t;
+        if (wave >= nwt || tile[0] >= P.n_tiles) break;
       for (int ln = 0; ln < gn; ++ln) {
         const int node = g0 + ln;
         const f32x4* w1 = smem + (size_t)ln * P.node_blocks * 64 + lane;   // [fi][kb][ms]
