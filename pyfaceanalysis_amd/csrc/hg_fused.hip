@@ -906,18 +906,30 @@ public:
                 continue;
             }
             if (s.kind == 2) {        // iGSFA layer
-                // waves x tiles per workgroup: the largest shape that still gives every CU a workgroup
-                // (the top layers have 16 .. 1 nodes: with 8 x 2 a single node would run on 16 CUs)
-                static const int ig_shapes[][2] = {{8, 2}, {4, 2}, {4, 1}, {2, 1}, {1, 1}};
-                int nwt = 1, T = 1;     // waves that take tiles x tiles per wave
-                for (auto& sh : ig_shapes) {
-                    const int64_t tg = (n_tiles + sh[0] * sh[1] - 1) / (sh[0] * sh[1]);
-                    if (sh[0] * sh[1] <= std::max(n_tiles, 1) && tg * s.n_nodes >= 256) {
-                        nwt = sh[0];
-                        T = sh[1];
-                        break;
+                // Waves that take tiles (nwt) x tiles per wave (T): the largest shape that still gives every CU
+                // a workgroup (the top layers have 16 .. 1 nodes: with 8 x 2 a single node would run on 16 CUs).
+                // Measured on the 11-layer net (us per layer, 4096 rows): 8x2 beats 4x2 / 16x1 / 8x1 wherever
+                // it fills the chip; T = 1 loses 30-50 % (half the MFMAs per A fragment read from LDS); waves
+                // per workgroup must be a multiple of 4 (6x2 places 2,2,1,1 waves on the SIMDs and a second
+                // workgroup no longer fits).  Nodes of 5-6 input blocks fit 3 waves per SIMD: 12x2 there.
+                const size_t ig_lds = (size_t)s.node_blocks * 1024 + (size_t)s.bias_floats * 4 + (size_t)s.kb1 * 8;
+                int nwt = 1, T = 1;
+                {
+                    static const int cand[][2] = {{12, 2}, {8, 2}, {4, 2}, {4, 1}, {2, 1}, {1, 1}};
+                    int forced_w = 0, forced_t = 0;
+                    if (const char* e2 = getenv("HIGSFA_IG_SHAPE")) sscanf(e2, "%d,%d", &forced_w, &forced_t);   // experiments
+                    for (auto& c : cand) {
+                        if (forced_w && (c[0] != forced_w || c[1] != forced_t)) continue;
+                        if (c[0] == 12 && !(s.kb1 == 5 || s.kb1 == 6)) continue;
+                        const int64_t tg = (n_tiles + c[0] * c[1] - 1) / (c[0] * c[1]);
+                        if (forced_w || (c[0] * c[1] <= std::max(n_tiles, 1) && tg * s.n_nodes >= 256) || (c[0] == 1 && c[1] == 1)) {
+                            nwt = c[0];
+                            T = c[1];
+                            break;
+                        }
                     }
                 }
+                const int ig_occ = resident_blocks(pick_igsfa(s.mt1, s.mt2, T, s.kb1), std::max(nwt, 4) * 64, ig_lds);
                 const int nw = std::max(nwt, 4);   // never fewer than 4 waves to copy a node's weights
                 P.nodes_per_wg = nwt;
                 P.ig_has_lr = s.ig_has_lr ? 1 : 0;
@@ -927,10 +939,11 @@ public:
                 const int npg = 1;   // one node per workgroup measured fastest (236/180 us vs 246-288/220-269 us with 32-96 KiB groups on the 11-layer net)
                 P.nodes_per_group = npg;
                 P.n_chunks = (s.n_nodes + npg - 1) / npg;
-                P.tile_parts = std::max(1, std::min(P.tile_groups, 512 / std::max(1, P.n_chunks)));
-                const size_t lds_bytes = (size_t)npg * (s.node_blocks * 1024 + (size_t)s.bias_floats * 4 + (size_t)s.kb1 * 8);
+                P.tile_parts = std::max(1, std::min(P.tile_groups, 256 * ig_occ / std::max(1, P.n_chunks)));
+                const size_t lds_bytes = ig_lds;
                 StageFn fn = pick_igsfa(s.mt1, s.mt2, T, s.kb1);
                 set_lds_limit(fn, lds_bytes);
+                if (getenv("HIGSFA_DEBUG")) fprintf(stderr, "[igsfa stage %d] nodes %d kb1 %d shape %dx%d occ %d lds %zu tile_groups %d parts %d\n", (int)si, s.n_nodes, s.kb1, nwt, T, ig_occ, lds_bytes, P.tile_groups, P.tile_parts);
                 hipLaunchKernelGGL(fn, (unsigned)(P.n_chunks * P.tile_parts), nw * 64, lds_bytes, st, P);
                 std::swap(cur, nxt);
                 if (ev) HG_HIP(hipEventRecord(ev[e++], st));

@@ -39,8 +39,8 @@ __global__ void __launch_bounds__(256) k_im2frag(const XT* __restrict__ x, int64
 //                                                                     IS the C operand (same layout)
 //   y[mo] += W3[kb][mo] * x0[kb]                    q = pca(r) lands in the remaining rows of y
 // Output tiles hold [s, q] in the caller's column order.
-template <int MS, int MO, int T, int KBM>   // KBM: K-block capacity of a node input (2 or 8; <= 128 inputs)
-__global__ void __launch_bounds__(512, (KBM <= 2 ? 4 : 2)) k_igsfa(StageParams P) {
+template <int MS, int MO, int T, int KBM>   // KBM: K-block capacity of a node input (2, 4, 6 or 8; <= 128 inputs)
+__global__ void __launch_bounds__((KBM == 6 ? 768 : 512), (KBM <= 4 ? 4 : KBM <= 6 ? 3 : 2)) k_igsfa(StageParams P) {
     extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, nw = nthr >> 6, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -171,7 +171,11 @@ __global__ void __launch_bounds__(512, (KBM <= 2 ? 4 : 2)) k_igsfa(StageParams P
 
 template <int MS, int MO>
 static StageFn pick_igsfa_t(int T, int kb1) {
+    // the input fragments of a node stay in registers through all three GEMMs: the block capacity sets the
+    // register count and with it the waves per SIMD (4 / 4 / 3 / 2)
     if (kb1 <= 2) return T == 2 ? (StageFn)k_igsfa<MS, MO, 2, 2> : (StageFn)k_igsfa<MS, MO, 1, 2>;
+    if (kb1 <= 4) return T == 2 ? (StageFn)k_igsfa<MS, MO, 2, 4> : (StageFn)k_igsfa<MS, MO, 1, 4>;
+    if (kb1 <= 6) return T == 2 ? (StageFn)k_igsfa<MS, MO, 2, 6> : (StageFn)k_igsfa<MS, MO, 1, 6>;
     return T == 2 ? (StageFn)k_igsfa<MS, MO, 2, 8> : (StageFn)k_igsfa<MS, MO, 1, 8>;
 }
 StageFn pick_igsfa(int ms, int mo, int T, int kb1) {   // ms <= mo (the slow features are a prefix of the output)
