@@ -14,7 +14,7 @@ os.makedirs(P, exist_ok=True)
 
 
 def short(n):
-    return n.replace("hg::(anonymous namespace)::", "").replace("(StageParams, StageParams)", "").replace("(StageParams)", "")
+    return n.replace("hg::(anonymous namespace)::", "").replace("hg::fused::", "").replace("(StageParams, StageParams)", "").replace("(StageParams)", "")
 
 
 def is_first(k):
@@ -35,7 +35,7 @@ def by_position(seq):
 
 
 def counters(d):
-    f = glob.glob(os.path.join(G, d, "*", "*_counter_collection.csv"))[0]
+    f = max(glob.glob(os.path.join(G, d, "*", "*_counter_collection.csv")), key=os.path.getmtime)   # newest run
     per = collections.OrderedDict()
     for r in csv.DictReader(open(f)):
         key = (int(r["Dispatch_Id"]), short(r["Kernel_Name"]), r["Grid_Size"])
@@ -44,9 +44,9 @@ def counters(d):
     return {key: v[-1] for key, v in by_position(seq).items()}     # last step's dispatch
 
 
-stats = glob.glob(os.path.join(G, "prof_" + tag, "*", "*_kernel_stats.csv"))[0]
+stats = max(glob.glob(os.path.join(G, "prof_" + tag, "*", "*_kernel_stats.csv")), key=os.path.getmtime)
 shutil.copy(stats, os.path.join(P, tag + "_kernel_stats.csv"))
-trace = glob.glob(os.path.join(G, "prof_" + tag, "*", "*_kernel_trace.csv"))[0]
+trace = max(glob.glob(os.path.join(G, "prof_" + tag, "*", "*_kernel_trace.csv")), key=os.path.getmtime)
 rows = sorted(csv.DictReader(open(trace)), key=lambda r: int(r["Start_Timestamp"]))
 dur = by_position([(short(r["Kernel_Name"]), r["Grid_Size_X"], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
                    for r in rows])
