@@ -553,6 +553,7 @@ constexpr int kWeightLdsKiB = 64;       // target size of a node group's weights
 struct HostStage {
     int mt1 = 1, mt2 = 1, mto = 1, nb_out = 0, nb_in = 0, n_nodes = 0, kb1 = 0, nf = 0;
     int node_blocks = 0, bias_floats = 0, nk_last = 4;
+    int p_max = 0, s_max = 0;   // widest first / second affine of the layer (real outputs)
     bool has_exp = false, contig4 = false, vec_ok = false;
     std::vector<ExpFunc> funcs;
     uint8_t nk2[kMaxMT][kMaxFuncs] = {};
@@ -601,7 +602,9 @@ public:
                 hs.mt1 = std::max(hs.mt1, (nd.A1.out + 15) / 16);
                 if (nd.has_exp) hs.mt2 = std::max(hs.mt2, (nd.A2.out + 15) / 16);
                 p_max = std::max(p_max, nd.A1.out);
+                if (nd.has_exp) hs.s_max = std::max(hs.s_max, nd.A2.out);
             }
+            hs.p_max = p_max;
             if (!hs.has_exp) hs.mt2 = 1;
             hs.mto = hs.has_exp ? hs.mt2 : hs.mt1;
             hs.nb_in = prev_nb;
@@ -971,7 +974,10 @@ public:
                 if (fuse01_ && P.vec4 && n_tiles >= 2) {
                     // layers 0 and 1 in one persistent kernel; layer 1 writes where its own launch would
                     StageParams Q = base_params(stages_[1], nullptr, cur);
-                    StageFn2 fn = pick_stage01p(x_dtype, false);
+                    // second tiles of both layer-1 affines hold <= 4 real rows: 4x4x1 MFMA form (HIGSFA_NO_REM4: off)
+                    const bool rem4 = stages_[1].p_max <= 20 && stages_[1].s_max <= 20 && stages_[1].nk2[1][0] <= 1 && stages_[1].nk2[1][1] <= 1 &&
+                                      !getenv("HIGSFA_NO_REM4");
+                    StageFn2 fn = pick_stage01p(x_dtype, false, rem4);
                     const int thr01 = 64 * std::max(1, (s.max_chunk_nodes + 1) / 2);   // one wave per pair of layer-0 nodes
                     // two tiles of T = 2 batch tiles + 10 vectors of 16 floats (means, biases) per wave
                     const size_t lds2 = (size_t)(kDoubleBuffer01 ? 2 : 1) * 2 * 16 * s.lds_stride * 4 + (size_t)(thr01 / 64) * 160 * 4;
@@ -993,7 +999,7 @@ public:
                     if (getenv("HIGSFA_DEBUG")) fprintf(stderr, "[front] occ %d threads %d lds %zu chunks %d tile_parts %d\n", occ, thr01, lds2, P.n_chunks, P.tile_parts);
                     const char* stamp_env = getenv("HIGSFA_STAMP");
                     if (stamp_env && atoi(stamp_env) == 0 && x_dtype == HG_F32) {
-                        fn = pick_stage01p(HG_F32, true);
+                        fn = pick_stage01p(HG_F32, true, rem4);
                         stamp_blocks_ = P.n_chunks * P.tile_parts;
                         stamp_buf_.alloc((size_t)stamp_blocks_ * 8 * 8 * 8);
                         HG_HIP(hipMemsetAsync(stamp_buf_.p, 0, stamp_buf_.bytes, st));

@@ -235,7 +235,26 @@ __global__ void __launch_bounds__(512) k_stage0p(StageParams P) {
 // layer-0 activation (64 KiB per sub-image written and read back) never exists in memory.
 // Requirements checked on the host: layer 0 as for k_stage0p; layer-1 node n reads exactly the
 // blocks of layer-0 nodes 2n and 2n+1; both layer-1 affines have <= 32 outputs; same <= 2 functions.
-template <typename XT, bool STAMP = false>
+// REM4: both layer-1 affines have 17..20 outputs, i.e. their second 16-row tile holds only four real rows
+// (features 16..19 sit at rows 0, 4, 8, 12 = lane group g, register 0).  Those tiles run on
+// v_mfma_f32_4x4x1_16B_f32 instead — 16 independent 4x4 blocks per instruction, 8 cycles instead of 32:
+// block b = lane / 4 takes k index g = lane / 16 of the k-step and sub-images 4 (b % 4) .. + 3, so the B
+// operand is the very same register as for the 16x16 form; A lane (g, i) holds W[row i][k]; the four k
+// partial sums (lane groups) are added with two cross-lane steps and lane group g keeps row g.
+// Same products, 3/4 of the padding multiplications of those tiles gone (22 % of this kernel's MFMA time).
+#define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ f32x4 rem4_rows(f32x4 d, int g) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        d[i] += __shfl_xor(d[i], 16);
+        d[i] += __shfl_xor(d[i], 32);
+    }
+    const float v = g == 0 ? d[0] : g == 1 ? d[1] : g == 2 ? d[2] : d[3];
+    return f32x4{v, 0.f, 0.f, 0.f};
+}
+
+template <typename XT, bool STAMP = false, bool REM4 = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 3))) k_stage01p(StageParams P, StageParams Q) {
     extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
     float* lds = (float*)smem;
@@ -311,6 +330,21 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 3))
                 *(f32x4*)(cst + (C_QB1 + mt) * 16 + g * 4) = *(const f32x4*)(bq + mt * 16);
                 *(f32x4*)(cst + (C_QB2 + mt) * 16 + g * 4) = *(const f32x4*)(bq + 32 + mt * 16);
             }
+    }
+    if constexpr (REM4) {
+        // 4x4 form of the second-tile fragments: lane (g, i = lane % 4) takes row 4 i of lane group g
+        const int src = ((lane & 48) | ((lane & 3) << 2)) << 2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+                q_a1[kb][1][r] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(q_a1[kb][1][r])));
+#pragma unroll
+            for (int m1 = 0; m1 < 2; ++m1)
+#pragma unroll
+                for (int fi = 0; fi < 2; ++fi)
+                    q_a2[m1][fi][1][r] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(q_a2[m1][fi][1][r])));
+        }
     }
     const int fk0 = P.funcp & 15, fk1 = (P.funcp >> 4) & 15;
     const float ex0 = P.expo[0], ex1 = P.expo[1];
@@ -407,25 +441,43 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 3))
                     z1[mt][t] = *(const f32x4*)(cst + (C_QB1 + mt) * 16 + g * 4);
                     y1[mt][t] = *(const f32x4*)(cst + (C_QB2 + mt) * 16 + g * 4);
                 }
+            f32x4 d4[T];      // REM4: 4x4-form accumulators of the second tile (rows x k partial sums)
+#pragma unroll
+            for (int t = 0; t < T; ++t) d4[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                for (int r = 0; r < 4; ++r) {
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt)
+                    for (int t = 0; t < T; ++t) z1[0][t] = MFMA16(q_a1[kb][0][r], y0[kb][t][r], z1[0][t]);
 #pragma unroll
-                        for (int t = 0; t < T; ++t) z1[mt][t] = MFMA16(q_a1[kb][mt][r], y0[kb][t][r], z1[mt][t]);
+                    for (int t = 0; t < T; ++t) {
+                        if constexpr (REM4) d4[t] = MFMA4(q_a1[kb][1][r], y0[kb][t][r], d4[t]);
+                        else z1[1][t] = MFMA16(q_a1[kb][1][r], y0[kb][t][r], z1[1][t]);
+                    }
+                }
+            if constexpr (REM4) {
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    z1[1][t] += rem4_rows(d4[t], g);
+                    d4[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
 #pragma unroll
             for (int fi = 0; fi < 2; ++fi) {        // z tile 0: full, branch-free
                 f32x4 e[T];
 #pragma unroll
                 for (int t = 0; t < T; ++t) e[t] = apply_func(fi == 0 ? qfk0 : qfk1, fi == 0 ? qex0 : qex1, z1[0][t]);
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                for (int r = 0; r < 4; ++r) {
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt)
+                    for (int t = 0; t < T; ++t) y1[0][t] = MFMA16(q_a2[0][fi][0][r], e[t][r], y1[0][t]);
 #pragma unroll
-                        for (int t = 0; t < T; ++t) y1[mt][t] = MFMA16(q_a2[0][fi][mt][r], e[t][r], y1[mt][t]);
+                    for (int t = 0; t < T; ++t) {
+                        if constexpr (REM4) d4[t] = MFMA4(q_a2[0][fi][1][r], e[t][r], d4[t]);
+                        else y1[1][t] = MFMA16(q_a2[0][fi][1][r], e[t][r], y1[1][t]);
+                    }
+                }
             }
 #pragma unroll
             for (int fi = 0; fi < 2; ++fi) {        // z tile 1: partial (runtime k-step count)
@@ -437,10 +489,17 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 3))
                 for (int r = 0; r < 4; ++r)
                     if (r < nk) {
 #pragma unroll
-                        for (int mt = 0; mt < 2; ++mt)
+                        for (int t = 0; t < T; ++t) y1[0][t] = MFMA16(q_a2[1][fi][0][r], e[t][r], y1[0][t]);
 #pragma unroll
-                            for (int t = 0; t < T; ++t) y1[mt][t] = MFMA16(q_a2[1][fi][mt][r], e[t][r], y1[mt][t]);
+                        for (int t = 0; t < T; ++t) {
+                            if constexpr (REM4) d4[t] = MFMA4(q_a2[1][fi][1][r], e[t][r], d4[t]);
+                            else y1[1][t] = MFMA16(q_a2[1][fi][1][r], e[t][r], y1[1][t]);
+                        }
                     }
+            }
+            if constexpr (REM4) {
+#pragma unroll
+                for (int t = 0; t < T; ++t) y1[1][t] += rem4_rows(d4[t], g);
             }
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
@@ -492,7 +551,12 @@ StageFn pick_stage0(int mt1, int mt2, int T, int x_dtype) {
 StageFn pick_stage0p(int x_dtype) {
     return x_dtype == HG_U8 ? (StageFn)k_stage0p<4, uint8_t> : x_dtype == HG_F32 ? (StageFn)k_stage0p<4, float> : (StageFn)k_stage0p<4, double>;
 }
-StageFn2 pick_stage01p(int x_dtype, bool stamp) {
+StageFn2 pick_stage01p(int x_dtype, bool stamp, bool rem4) {
+    if (rem4) {
+        if (stamp && x_dtype == HG_F32) return (StageFn2)k_stage01p<float, true, true>;
+        return x_dtype == HG_U8 ? (StageFn2)k_stage01p<uint8_t, false, true>
+                                : x_dtype == HG_F32 ? (StageFn2)k_stage01p<float, false, true> : (StageFn2)k_stage01p<double, false, true>;
+    }
     if (stamp && x_dtype == HG_F32) return (StageFn2)k_stage01p<float, true>;
     return x_dtype == HG_U8 ? (StageFn2)k_stage01p<uint8_t> : x_dtype == HG_F32 ? (StageFn2)k_stage01p<float> : (StageFn2)k_stage01p<double>;
 }
