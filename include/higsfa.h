@@ -155,7 +155,8 @@ int hg_patcher_extract(hg_patcher* p, const void* frame, int frame_dtype, int fr
  * Not on the reference's path (it never trains, face_analysis.py:451-479); restates
  * mdp.nodes.SFANode train/stop_training per node k over input columns conn[k*d .. (k+1)*d):
  * mean, B = Cov(x), A = Cov(x[t+1]-x[t]) accumulated in fp64 by a HIP kernel, then
- * A w = lambda B w by rocSOLVER dsygvj (batched Jacobi; HIGSFA_SYGVD=1: dsygvd; eigenvalues ascending, w' B w = 1).
+ * A w = lambda B w (eigenvalues ascending, w' B w = 1): hand-written Jacobi kernel for d <= 16, rocSOLVER dsygvj
+ * for wider nodes (HIGSFA_SYGVJ=1 / HIGSFA_SYGVD=1 force rocSOLVER's dsygvj / dsygvd).
  * x: (n, ldx) matrix in time order, a device pointer or (x_on_host != 0) a host pointer that is
  * copied to the device first.  Host outputs: evals (n_nodes, d), evecs
  * (n_nodes, d, d) column-major per node (column i = eigenvector i), mean (n_nodes, d);

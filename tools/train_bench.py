@@ -42,5 +42,5 @@ for k in (0, 511, 1023):
     worst_vec = max(worst_vec, float(np.abs(np.diag(np.abs(v.T @ B @ evecs[k])) - 1).max()))
 flops = n * 1024.0 * (16 * 16 * 2) * 2
 print("SFA train step: %d patches of 128x128 (uint8, %.2f GB), 1024 nodes x 16: statistics %.1f ms (%.1f GFLOP/s fp64, %.0f GB/s of input), "
-      "generalized eigen-solve (rocSOLVER dsygvj) %.1f ms, wall %.1f ms; eigenvalues vs scipy %.1e, eigenvectors %.1e (budget 1e-5)"
+      "generalized eigen-solve %.2f ms, wall %.1f ms; eigenvalues vs scipy %.1e, eigenvectors %.1e (budget 1e-5)"
       % (n, n * side * side / 1e9, tms[0], flops / tms[0] / 1e6, n * side * side / tms[0] / 1e6, tms[1], wall * 1e3, worst_val, worst_vec))
