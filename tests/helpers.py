@@ -123,3 +123,52 @@ def fuzz_net(seed):
         if w * h == 1:
             break
     return flow
+
+
+def fuzz_igsfa_net(seed):
+    """Random hierarchy of iGSFA nodes: random widths, with / without the linear
+    reconstruction and the expansion, merges in x / y / 2x2, uneven slow-feature counts across layers."""
+    rng = np.random.default_rng(5000 + seed)
+    w, h = (int(v) for v in rng.choice([4, 6, 8], 2))
+    fx, fy = (int(v) for v in rng.choice([2, 3, 4], 2))
+    fx, fy = min(fx, w), min(fy, h)
+    while w % fx:
+        fx -= 1
+    while h % fy:
+        fy -= 1
+    flow, c = [], 1
+    for depth in range(int(rng.integers(1, 4))):
+        if depth:
+            fx, fy = [(2, 1), (1, 2), (2, 2)][int(rng.integers(0, 3))]
+            fx, fy = min(fx, w), min(fy, h)
+            while w % fx:
+                fx -= 1
+            while h % fy:
+                fy -= 1
+        sb = N.Rectangular2dSwitchboard((w, h), (fx, fy), (fx, fy), c)
+        n_nodes, d_in = sb.output_channels, sb.out_channel_dim
+        if d_in > 128:
+            break
+        k = int(rng.integers(1, min(d_in, 30) + 1))           # slow features (all preserved)
+        q = int(rng.integers(1, min(d_in, 64 - k) + 1))      # pca part
+        with_lr = rng.random() < 0.8
+        funcs = [N.identity, N.unsigned_08expo] if rng.random() < 0.7 else [N.identity]
+        if rng.random() < 0.2:
+            funcs = [N.identity, N.signed_expo(float(rng.uniform(0.6, 1.1)))]
+
+        def make():
+            ex = N.GeneralExpansionNode(funcs, d_in)
+            sfa = rand_sfa(rng, ex.output_dim, k, N.GSFANode)
+            lr = N.LinearRegressionNode(rng.normal(size=(k + 1, d_in)) / np.sqrt(k + 1))
+            pca = rand_pca(rng, d_in, q)
+            pca.avg = np.zeros_like(pca.avg)                   # the residual is centred by construction
+            return N.iGSFANode(rng.normal(size=d_in), ex, sfa, rng.uniform(0.5, 2.0, size=k), lr, pca, k,
+                               reconstruct_with_sfa=with_lr)
+
+        layer = N.Layer([make() for _ in range(n_nodes)])
+        flow += [sb, layer]
+        w, h = sb.out_channels_xy
+        c = k + q
+        if w * h == 1:
+            break
+    return flow

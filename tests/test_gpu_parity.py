@@ -80,6 +80,24 @@ def test_fuzzed_hierarchies(native_lib, seed):
         flow.close()
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzzed_igsfa_hierarchies(native_lib, seed):
+    """Random iGSFA hierarchies (helpers.fuzz_igsfa_net): fused three-GEMM node kernel (and the generic plan on
+    every fourth seed) against the oracle."""
+    nodes = helpers.fuzz_igsfa_net(seed)
+    n = [1, 16, 17, 50][seed % 4]
+    x = np.random.default_rng(seed).normal(size=(n, nodes[0].input_dim)) * 1.5
+    ref = oracle.execute_flow(nodes, x)
+    flow = Flow(nodes)
+    assert flow.info().plan_kind == _capi.HG_PLAN_FUSED
+    assert rel_err(flow.execute(x), ref) <= TOL
+    flow.close()
+    if seed % 4 == 0:
+        flow = Flow(nodes, force_generic=True)
+        assert rel_err(flow.execute(x), ref) <= TOL
+        flow.close()
+
+
 @pytest.mark.parametrize("force_generic", [True, False])
 def test_u11l_128_matches_oracle(native_lib, nets, force_generic):
     """BASELINE.json configs[0]: the 11-layer net on 256 sub-images of 128x128."""
