@@ -24,6 +24,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <map>
 #include <sstream>
 #include <tuple>
@@ -126,6 +127,78 @@ bool to_chains(const TNode& n, std::vector<ChainT>& out, std::string& why) {
     return one(n);
 }
 
+// An iGSFA node is ONE affine map of its expanded input when the expansion contains the identity over all
+// columns (e P = x0 for a selection matrix P):
+//     s = e Ws + cs,           cs = bs - as Ws                       (scale already folded into Ws, bs)
+//     l = e (Ws Wl) + cl,      cl = (cs - al) Wl + bl                (reconstruction, when present)
+//     q = e (P - Ws Wl) Wp + (-cl - ap) Wp + bp
+// so y = [s, q] = e [Ws | (P - Ws Wl) Wp] + const, folded here in float64.  Nodes of up to 64 inputs then run
+// as ordinary nodes (first affine = x - mean, second = the folded map) on the kernels tuned for them —
+// including the fused first-two-layers kernel, which also makes the k_im2frag pass unnecessary; the MFMA
+// count is about the same (one GEMM over 2 d_in instead of three smaller ones).  Wider nodes keep the
+// three-GEMM k_igsfa (their identity first affine would need more than kMaxMT tiles).  HIGSFA_IG_NOFOLD=1
+// keeps every iGSFA node on k_igsfa (tests).
+void fold_igsfa(FNode& fn) {
+    const int d = fn.in_dim, k = fn.ig_k, q = fn.ig_pca.out;
+    if (d > 16 * kMaxMT || getenv("HIGSFA_IG_NOFOLD")) return;
+    int E = 0, id_off = -1;
+    for (const ExpFunc& f : fn.funcs) {
+        if (f.kind == E_IDENTITY && f.used(d) == d && id_off < 0) id_off = E;
+        E += f.out_dim(d);
+    }
+    if (id_off < 0 || fn.ig_sfa.in != E || fn.ig_sfa.out != k) return;
+    const Aff &S = fn.ig_sfa, &Lr = fn.ig_lr, &Pc = fn.ig_pca;
+    std::vector<double> cs(k), Wsl((size_t)E * d, 0.0), cl(d, 0.0);
+    for (int j = 0; j < k; ++j) {
+        double v = S.b[j];
+        for (int e = 0; e < E; ++e) v -= S.a[e] * S.W[(size_t)e * k + j];
+        cs[j] = v;
+    }
+    if (fn.ig_has_lr) {
+        for (int e = 0; e < E; ++e)
+            for (int j = 0; j < k; ++j) {
+                const double w = S.W[(size_t)e * k + j];
+                if (w == 0.0) continue;
+                for (int c = 0; c < d; ++c) Wsl[(size_t)e * d + c] += w * Lr.W[(size_t)j * d + c];
+            }
+        for (int c = 0; c < d; ++c) {
+            double v = Lr.b[c];
+            for (int j = 0; j < k; ++j) v += (cs[j] - Lr.a[j]) * Lr.W[(size_t)j * d + c];
+            cl[c] = v;
+        }
+    }
+    Aff A2;
+    A2.in = E;
+    A2.out = k + q;
+    A2.a.assign(E, 0.0);
+    A2.W.assign((size_t)E * (k + q), 0.0);
+    A2.b.assign(k + q, 0.0);
+    for (int e = 0; e < E; ++e) {
+        for (int j = 0; j < k; ++j) A2.W[(size_t)e * (k + q) + j] = S.W[(size_t)e * k + j];
+        for (int c = 0; c < d; ++c) {
+            const double m = ((e == id_off + c) ? 1.0 : 0.0) - Wsl[(size_t)e * d + c];
+            if (m == 0.0) continue;
+            for (int j = 0; j < q; ++j) A2.W[(size_t)e * (k + q) + k + j] += m * Pc.W[(size_t)c * q + j];
+        }
+    }
+    for (int j = 0; j < k; ++j) A2.b[j] = cs[j];
+    for (int j = 0; j < q; ++j) {
+        double v = Pc.b[j];
+        for (int c = 0; c < d; ++c) v += (-cl[c] - Pc.a[c]) * Pc.W[(size_t)c * q + j];
+        A2.b[k + j] = v;
+    }
+    Aff A1;
+    A1.in = A1.out = d;
+    A1.a = fn.ig_mean;
+    A1.a.resize(d, 0.0);
+    A1.W.assign((size_t)d * d, 0.0);
+    for (int c = 0; c < d; ++c) A1.W[(size_t)c * d + c] = 1.0;
+    A1.b.assign(d, 0.0);
+    fn.A1 = std::move(A1);
+    fn.A2 = std::move(A2);
+    fn.is_ig = false;
+}
+
 bool canon(const ChainT& c, int in_off, FNode& fn, std::string& why) {
     fn.in_off = in_off;
     fn.in_dim = c.in_dim;
@@ -155,6 +228,7 @@ bool canon(const ChainT& c, int in_off, FNode& fn, std::string& why) {
                 fn.funcs = {ExpFunc{E_IDENTITY, 0, 0, 1.0}};
             }
             fn.has_exp = true;
+            fold_igsfa(fn);
             return true;
         }
     int phase = 0;  // 0: before A1, 1: in A1, 2: after E, 3: in A2

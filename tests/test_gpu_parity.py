@@ -81,9 +81,12 @@ def test_fuzzed_hierarchies(native_lib, seed):
 
 
 @pytest.mark.parametrize("seed", range(12))
-def test_fuzzed_igsfa_hierarchies(native_lib, seed):
-    """Random iGSFA hierarchies (helpers.fuzz_igsfa_net): fused three-GEMM node kernel (and the generic plan on
-    every fourth seed) against the oracle."""
+def test_fuzzed_igsfa_hierarchies(native_lib, seed, monkeypatch):
+    """Random iGSFA hierarchies (helpers.fuzz_igsfa_net) against the oracle.  Nodes of up to 64 inputs are folded
+    on the host into ordinary nodes; odd seeds switch the folding off (HIGSFA_IG_NOFOLD, read at plan time) so
+    that the three-GEMM node kernel is exercised at every width; every fourth seed also runs the generic plan."""
+    if seed % 2:
+        monkeypatch.setenv("HIGSFA_IG_NOFOLD", "1")
     nodes = helpers.fuzz_igsfa_net(seed)
     n = [1, 16, 17, 50][seed % 4]
     x = np.random.default_rng(seed).normal(size=(n, nodes[0].input_dim)) * 1.5
