@@ -135,18 +135,19 @@ bool to_chains(const TNode& n, std::vector<ChainT>& out, std::string& why) {
 // so y = [s, q] = e [Ws | (P - Ws Wl) Wp] + const, folded here in float64.  Nodes of up to 64 inputs then run
 // as ordinary nodes (first affine = x - mean, second = the folded map) on the kernels tuned for them —
 // including the fused first-two-layers kernel, which also makes the k_im2frag pass unnecessary; the MFMA
-// count is about the same (one GEMM over 2 d_in instead of three smaller ones).  Wider nodes keep the
-// three-GEMM k_igsfa (their identity first affine would need more than kMaxMT tiles).  HIGSFA_IG_NOFOLD=1
-// keeps every iGSFA node on k_igsfa (tests).
-void fold_igsfa(FNode& fn) {
+// count is about the same (one GEMM over 2 d_in instead of three smaller ones).  Wider nodes stay on k_igsfa
+// (their identity first affine would need more than kMaxMT tiles) but use the same folded map there: one GEMM
+// from the expanded input fragments to all output tiles instead of the G1 -> G2 -> G3 chain.
+// HIGSFA_IG_NOFOLD=1 keeps every iGSFA node on the three-GEMM form (tests).
+bool igsfa_affine(const FNode& fn, Aff& A2) {
     const int d = fn.in_dim, k = fn.ig_k, q = fn.ig_pca.out;
-    if (d > 16 * kMaxMT || getenv("HIGSFA_IG_NOFOLD")) return;
+    if (getenv("HIGSFA_IG_NOFOLD")) return false;
     int E = 0, id_off = -1;
     for (const ExpFunc& f : fn.funcs) {
         if (f.kind == E_IDENTITY && f.used(d) == d && id_off < 0) id_off = E;
         E += f.out_dim(d);
     }
-    if (id_off < 0 || fn.ig_sfa.in != E || fn.ig_sfa.out != k) return;
+    if (id_off < 0 || fn.ig_sfa.in != E || fn.ig_sfa.out != k) return false;
     const Aff &S = fn.ig_sfa, &Lr = fn.ig_lr, &Pc = fn.ig_pca;
     std::vector<double> cs(k), Wsl((size_t)E * d, 0.0), cl(d, 0.0);
     for (int j = 0; j < k; ++j) {
@@ -167,7 +168,7 @@ void fold_igsfa(FNode& fn) {
             cl[c] = v;
         }
     }
-    Aff A2;
+    A2 = Aff();
     A2.in = E;
     A2.out = k + q;
     A2.a.assign(E, 0.0);
@@ -187,6 +188,13 @@ void fold_igsfa(FNode& fn) {
         for (int c = 0; c < d; ++c) v += (-cl[c] - Pc.a[c]) * Pc.W[(size_t)c * q + j];
         A2.b[k + j] = v;
     }
+    return true;
+}
+
+void fold_igsfa(FNode& fn) {
+    const int d = fn.in_dim;
+    Aff A2;
+    if (d > 16 * kMaxMT || !igsfa_affine(fn, A2)) return;
     Aff A1;
     A1.in = A1.out = d;
     A1.a = fn.ig_mean;
@@ -641,7 +649,7 @@ struct HostStage {
     int lds_stride = 0, max_chunk_nodes = 0, max_chunk_pieces = 0;
     int kind = 0;            // 0: affine-expansion-affine layer, 1: row-major -> fragment gather, 2: iGSFA layer
     bool from_x = false;     // reads the caller's row-major matrix
-    bool ig_has_lr = false;
+    bool ig_has_lr = false, ig_folded = false;
     int ig_nks[kMaxMT] = {};  // k-steps of each slow-feature tile
     std::vector<int32_t> gcol;
     DevBuf d_gcol;
@@ -986,30 +994,39 @@ public:
                 // Waves that take tiles (nwt) x tiles per wave (T): the largest shape that still gives every CU
                 // a workgroup (the top layers have 16 .. 1 nodes: with 8 x 2 a single node would run on 16 CUs).
                 // Measured on the 11-layer net (us per layer, 4096 rows): 8x2 beats 4x2 / 16x1 / 8x1 wherever
-                // it fills the chip; T = 1 loses 30-50 % (half the MFMAs per A fragment read from LDS); waves
+                // it fills the chip; T = 1 loses 30-50 % (half the MFMAs per A fragment read from LDS) even where it
+                // is the only way to give every CU a workgroup; waves
                 // per workgroup must be a multiple of 4 (6x2 places 2,2,1,1 waves on the SIMDs and a second
                 // workgroup no longer fits).  Nodes of 5-6 input blocks fit 3 waves per SIMD: 12x2 there.
                 const size_t ig_lds = (size_t)s.node_blocks * 1024 + (size_t)s.bias_floats * 4 + (size_t)s.kb1 * 8;
                 int nwt = 1, T = 1;
                 {
-                    static const int cand[][2] = {{12, 2}, {8, 2}, {4, 2}, {4, 1}, {2, 1}, {1, 1}};
+                    static const int cand[][2] = {{12, 2}, {8, 2}, {4, 2}};
                     int forced_w = 0, forced_t = 0;
                     if (const char* e2 = getenv("HIGSFA_IG_SHAPE")) sscanf(e2, "%d,%d", &forced_w, &forced_t);   // experiments
                     for (auto& c : cand) {
                         if (forced_w && (c[0] != forced_w || c[1] != forced_t)) continue;
                         if (c[0] == 12 && !(s.kb1 == 5 || s.kb1 == 6)) continue;
                         const int64_t tg = (n_tiles + c[0] * c[1] - 1) / (c[0] * c[1]);
-                        if (forced_w || (c[0] * c[1] <= std::max(n_tiles, 1) && tg * s.n_nodes >= 256) || (c[0] == 1 && c[1] == 1)) {
+                        if (forced_w || (c[0] * c[1] <= std::max(n_tiles, 1) && tg * s.n_nodes >= 256)) {
                             nwt = c[0];
                             T = c[1];
                             break;
                         }
+                    }
+                    if (nwt == 1 && T == 1 && !forced_w) {
+                        // too few (node, tile) pairs to fill the chip: still two tiles per wave — 4 x 2 with 32
+                        // workgroups beats 1 x 1 with 256 by a third on the single top node (every workgroup
+                        // copies the node's 64-80 KiB of weights, and T = 1 halves the MFMAs per LDS read)
+                        T = n_tiles >= 2 ? 2 : 1;
+                        nwt = n_tiles >= 8 ? 4 : n_tiles >= 4 ? 2 : 1;
                     }
                 }
                 const int ig_occ = resident_blocks(pick_igsfa(s.mt1, s.mt2, T, s.kb1), std::max(nwt, 4) * 64, ig_lds);
                 const int nw = std::max(nwt, 4);   // never fewer than 4 waves to copy a node's weights
                 P.nodes_per_wg = nwt;
                 P.ig_has_lr = s.ig_has_lr ? 1 : 0;
+                P.ig_folded = s.ig_folded ? 1 : 0;
                 P.nk2p[0] = 0;
                 for (int ms = 0; ms < s.mt1; ++ms) P.nk2p[0] |= (uint32_t)s.ig_nks[ms] << (4 * ms);
                 P.tile_groups = (n_tiles + nwt * T - 1) / (nwt * T);
@@ -1443,12 +1460,18 @@ private:
             hs.kb1 = std::max(hs.kb1, (int)K.src.size());
         }
         if (hs.kb1 > 8) fail(HG_ERR_FORMAT, "fused: iGSFA node input spans more than 8 source blocks");
-        const int KB = hs.kb1, MS = (k_max + 15) / 16, MO = (out_max + 15) / 16, nf = hs.nf;
+        // folded form (see igsfa_affine): one GEMM from the expanded input to all output tiles
+        std::vector<Aff> folded_a2(n);
+        bool folded = true;
+        for (int ni = 0; ni < n && folded; ++ni) folded = igsfa_affine(st.nodes[ni], folded_a2[ni]);
+        hs.ig_folded = folded;
+        if (folded) hs.ig_has_lr = false;
+        const int KB = hs.kb1, MO = (out_max + 15) / 16, MS = folded ? MO : (k_max + 15) / 16, nf = hs.nf;
         hs.mt1 = MS;
         hs.mt2 = MO;
         hs.mto = MO;
         for (int ms = 0; ms < MS; ++ms) hs.ig_nks[ms] = (std::min(16, k_max - 16 * ms) + 3) / 4;
-        hs.node_blocks = nf * KB * MS + KB * MS + KB * MO;
+        hs.node_blocks = folded ? nf * KB * MO : nf * KB * MS + KB * MS + KB * MO;
         hs.bias_floats = MO * 16 + 2 * KB * 16;
         if ((size_t)hs.node_blocks * 1024 + (size_t)hs.bias_floats * 4 + (size_t)KB * 8 > 150 * 1024)
             fail(HG_ERR_FORMAT, "fused: one iGSFA node needs %d KiB of weight fragments, more than a workgroup's LDS", hs.node_blocks);
@@ -1479,12 +1502,23 @@ private:
                 hs.kb1tab[((size_t)ni * KB + kb) * 2] = real ? K.src[kb] : K.src[0];
                 hs.kb1tab[((size_t)ni * KB + kb) * 2 + 1] = real ? K.nk[kb] : 0;
                 if (!real) continue;
-                hs.mfma_per_tile += (int64_t)K.nk[kb] * (nf * MS + MO);
+                hs.mfma_per_tile += (int64_t)K.nk[kb] * (folded ? nf * MO : nf * MS + MO);
                 for (int ms = 0; ms < MS && hs.ig_has_lr; ++ms) hs.mfma_per_tile += hs.ig_nks[ms];
                 for (int lane = 0; lane < 64; ++lane) {
                     const int i = lane & 15, gg = lane >> 4;
                     for (int r = 0; r < 4; ++r) {
                         const int cs = K.pos[kb * 16 + 4 * r + gg];           // input position of this k-slot
+                        if (folded) {     // rows = all output features, k-slots = expanded input positions
+                            const Aff& F = folded_a2[ni];
+                            for (int fi = 0; fi < nf; ++fi)
+                                for (int mo = 0; mo < MO; ++mo) {
+                                    const int f = 16 * mo + q_of_row(i);
+                                    if (f < k + Q && cs >= 0 && cs < used[fi])
+                                        w1[(((size_t)fi * KB + kb) * MO + mo) * 256 + lane * 4 + r] =
+                                            (float)F.W[(size_t)(foff[fi] + cs) * (k + Q) + f];
+                                }
+                            continue;
+                        }
                         // W1: rows = slow features, k-slots = expanded input positions
                         for (int fi = 0; fi < nf; ++fi)
                             for (int ms = 0; ms < MS; ++ms) {
@@ -1526,7 +1560,9 @@ private:
                     for (int r = 0; r < 4; ++r) {
                         const int f = 16 * mo + 4 * r + gg;
                         double v = 0;
-                        if (f < k) {
+                        if (folded) {
+                            if (f < k + Q) v = folded_a2[ni].b[f];
+                        } else if (f < k) {
                             v = nd.ig_sfa.b[f];
                             for (int e = 0; e < nd.ig_sfa.in; ++e) v -= nd.ig_sfa.a[e] * nd.ig_sfa.W[(size_t)e * k + f];
                         } else if (f < k + Q) {
@@ -1547,7 +1583,7 @@ private:
         max_nb_ = std::max(max_nb_, hs.nb_out);
         padded_flops_ += hs.mfma_per_tile * 2048 / 16;
         std::ostringstream os;
-        os << "fused iGSFA stage: " << n << " nodes, K-blocks " << KB << ", slow tiles " << MS << ", out tiles " << MO << ", "
+        os << "fused iGSFA stage" << (folded ? " (folded to one GEMM)" : "") << ": " << n << " nodes, K-blocks " << KB << ", slow tiles " << MS << ", out tiles " << MO << ", "
            << hs.mfma_per_tile << " MFMA/tile, " << hs.afrag.size() * 4 / 1024 << " KiB weights";
         hs.name = os.str();
     }

@@ -51,7 +51,7 @@ struct StageParams {
     const void* x;
     int64_t ldx, n_rows;
     int32_t lds_stride, nk_last, vec4, contig4;
-    int32_t ig_has_lr;
+    int32_t ig_has_lr, ig_folded;   // k_igsfa: residual GEMM present; folded form (first GEMM covers all output tiles, no others)
     unsigned long long* stamps;   // diagnostic build only (HIGSFA_STAMP): per-wave cycle stamps
 };
 

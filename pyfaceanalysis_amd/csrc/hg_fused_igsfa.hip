@@ -110,26 +110,33 @@ __global__ void __launch_bounds__((KBM == 6 ? 768 : 512), (KBM <= 4 ? 4 : KBM <=
 #pragma unroll
             for (int t = 0; t < T; ++t) y[mo][t] = bb;
         }
-        // G1: slow features from the expanded input
-        for (int fi = 0; fi < nf; ++fi) {
-            const int fk = (P.funcp >> (4 * fi)) & 15;
-            const float ex = P.expo[fi];
+        // G1: slow features (folded form: all output features) from the expanded input.  The A fragments are
+        // consumed in LDS order, one (function, block, tile) step after the other: the next one is always in
+        // flight while the current one is multiplied (a lone wave per SIMD has nothing else to hide the read).
+        {
+            const f32x4* wq = w1;
+            f32x4 a_nx = *wq;
+            for (int fi = 0; fi < nf; ++fi) {
+                const int fk = (P.funcp >> (4 * fi)) & 15;
+                const float ex = P.expo[fi];
 #pragma unroll
-            for (int kb = 0; kb < KBM; ++kb) {
-                if (kb >= kb1) continue;
-                f32x4 e[T];
+                for (int kb = 0; kb < KBM; ++kb) {
+                    if (kb >= kb1) continue;
+                    f32x4 e[T];
 #pragma unroll
-                for (int t = 0; t < T; ++t) e[t] = apply_func(fk, ex, x0[kb][t]);
-                const f32x4* wp = w1 + ((size_t)(fi * kb1 + kb) * MS) * 64;
+                    for (int t = 0; t < T; ++t) e[t] = apply_func(fk, ex, x0[kb][t]);
 #pragma unroll
-                for (int ms = 0; ms < MS; ++ms) {      // only the tiles that hold slow features
-                    const f32x4 a = wp[ms * 64];
+                    for (int ms = 0; ms < MS; ++ms) {      // only the tiles that hold slow features
+                        const f32x4 a = a_nx;
+                        wq += 64;
+                        a_nx = *wq;                        // past the last step: the next block of this node's LDS image, unused
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (r < nk1[kb]) {
+                        for (int r = 0; r < 4; ++r)
+                            if (r < nk1[kb]) {
 #pragma unroll
-                            for (int t = 0; t < T; ++t) y[ms][t] = MFMA16(a[r], e[t][r], y[ms][t]);
-                        }
+                                for (int t = 0; t < T; ++t) y[ms][t] = MFMA16(a[r], e[t][r], y[ms][t]);
+                            }
+                    }
                 }
             }
         }
@@ -154,11 +161,13 @@ __global__ void __launch_bounds__((KBM == 6 ? 768 : 512), (KBM <= 4 ? 4 : KBM <=
                 }
             }
         }
-        // G3: q = pca(r) into the remaining rows of the output tiles
+        // G3: q = pca(r) into the remaining rows of the output tiles (folded form: G1 already produced them)
+        if (!P.ig_folded) {
 #pragma unroll
-        for (int kb = 0; kb < KBM; ++kb) {
-            if (kb >= kb1) continue;
-            gemm_block<MO, T>(w3 + ((size_t)kb * MO) * 64, x0[kb], y, nk1[kb]);
+            for (int kb = 0; kb < KBM; ++kb) {
+                if (kb >= kb1) continue;
+                gemm_block<MO, T>(w3 + ((size_t)kb * MO) * 64, x0[kb], y, nk1[kb]);
+            }
         }
 #pragma unroll
         for (int mo = 0; mo < MO; ++mo)
