@@ -42,16 +42,23 @@ def test_blob_roundtrip_is_stable():
         assert b1 == b2 and len(b1) % 8 == 0
 
 
-def test_plans(native_lib, nets):
+def test_plans(native_lib, nets, monkeypatch):
     inf, desc = Flow(nets("T5L-16")).host_plan()
     assert inf.plan_kind == _capi.HG_PLAN_FUSED and inf.input_dim == 256 and inf.output_dim == 10
     assert inf.flops_per_row == synth.flops_per_row(nets("T5L-16")) and inf.padded_flops_per_row >= inf.flops_per_row
     assert Flow(nets("T5L-16", layout="separate")).host_plan()[0].plan_kind == _capi.HG_PLAN_FUSED
     assert Flow(helpers.overlapping_net()).host_plan()[0].plan_kind == _capi.HG_PLAN_FUSED
     assert Flow(helpers.linear_net()).host_plan()[0].plan_kind == _capi.HG_PLAN_FUSED
+    # iGSFA nodes of up to 64 inputs are folded into ordinary nodes on the host ...
+    inf, desc = Flow(nets("T5L-16", node_kind="igsfa")).host_plan()
+    assert inf.plan_kind == _capi.HG_PLAN_FUSED and "iGSFA stage" not in desc and "fused gather" not in desc
+    assert inf.padded_flops_per_row >= inf.flops_per_row > 0
+    # ... unless told not to: gather pre-pass + three-GEMM node kernel
+    monkeypatch.setenv("HIGSFA_IG_NOFOLD", "1")
     inf, desc = Flow(nets("T5L-16", node_kind="igsfa")).host_plan()
     assert inf.plan_kind == _capi.HG_PLAN_FUSED and "fused gather" in desc and "fused iGSFA stage" in desc
-    assert inf.padded_flops_per_row >= inf.flops_per_row > 0
+    assert "folded" not in desc
+    monkeypatch.delenv("HIGSFA_IG_NOFOLD")
     inf, desc = Flow(helpers.product_net()).host_plan()
     assert inf.plan_kind == _capi.HG_PLAN_GENERIC and "fused plan not used" in desc
     assert Flow(nets("T5L-16"), force_generic=True).host_plan()[0].plan_kind == _capi.HG_PLAN_GENERIC
@@ -64,6 +71,10 @@ def test_u11l_128_plan(native_lib, nets):
     assert inf.plan_kind == _capi.HG_PLAN_FUSED and inf.n_stages == 12
     assert inf.flops_per_row == 11017088 and inf.padded_flops_per_row == 13731840
     assert inf.input_dim == 16384 and inf.output_dim == 60 and inf.n_top_nodes == 22
+    # iGSFA variant: three ordinary (folded) layers, then wide nodes on the node kernel in its folded form
+    inf, desc = Flow(nets("U11L-128", node_kind="igsfa")).host_plan()
+    assert inf.plan_kind == _capi.HG_PLAN_FUSED and inf.n_stages == 12
+    assert desc.count("fused iGSFA stage (folded to one GEMM)") == 8 and "fused gather" not in desc
 
 
 def test_malformed_blobs_are_rejected(native_lib):
