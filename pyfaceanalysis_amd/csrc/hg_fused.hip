@@ -1006,7 +1006,7 @@ public:
                     if (const char* e2 = getenv("HIGSFA_IG_SHAPE")) sscanf(e2, "%d,%d", &forced_w, &forced_t);   // experiments
                     for (auto& c : cand) {
                         if (forced_w && (c[0] != forced_w || c[1] != forced_t)) continue;
-                        if (c[0] == 12 && !(s.kb1 == 5 || s.kb1 == 6)) continue;
+                        if (c[0] == 12 && (s.ig_folded || !(s.kb1 == 5 || s.kb1 == 6))) continue;   // k_igfold: <= 8 waves
                         const int64_t tg = (n_tiles + c[0] * c[1] - 1) / (c[0] * c[1]);
                         if (forced_w || (c[0] * c[1] <= std::max(n_tiles, 1) && tg * s.n_nodes >= 256)) {
                             nwt = c[0];
@@ -1022,7 +1022,10 @@ public:
                         nwt = n_tiles >= 8 ? 4 : n_tiles >= 4 ? 2 : 1;
                     }
                 }
-                const int ig_occ = resident_blocks(pick_igsfa(s.mt1, s.mt2, T, s.kb1), std::max(nwt, 4) * 64, ig_lds);
+                // folded layers stream their input blocks (k_igfold); HIGSFA_IG_RESIDENT=1 keeps them on k_igsfa
+                const bool igfold = s.ig_folded && !getenv("HIGSFA_IG_RESIDENT");
+                StageFn fn = igfold ? pick_igfold(s.mt2, T) : pick_igsfa(s.mt1, s.mt2, T, s.kb1);
+                const int ig_occ = resident_blocks(fn, std::max(nwt, 4) * 64, ig_lds);
                 const int nw = std::max(nwt, 4);   // never fewer than 4 waves to copy a node's weights
                 P.nodes_per_wg = nwt;
                 P.ig_has_lr = s.ig_has_lr ? 1 : 0;
@@ -1035,7 +1038,6 @@ public:
                 P.n_chunks = (s.n_nodes + npg - 1) / npg;
                 P.tile_parts = std::max(1, std::min(P.tile_groups, 256 * ig_occ / std::max(1, P.n_chunks)));
                 const size_t lds_bytes = ig_lds;
-                StageFn fn = pick_igsfa(s.mt1, s.mt2, T, s.kb1);
                 set_lds_limit(fn, lds_bytes);
                 if (getenv("HIGSFA_DEBUG")) fprintf(stderr, "[igsfa stage %d] nodes %d kb1 %d shape %dx%d occ %d lds %zu tile_groups %d parts %d\n", (int)si, s.n_nodes, s.kb1, nwt, T, ig_occ, lds_bytes, P.tile_groups, P.tile_parts);
                 hipLaunchKernelGGL(fn, (unsigned)(P.n_chunks * P.tile_parts), nw * 64, lds_bytes, st, P);

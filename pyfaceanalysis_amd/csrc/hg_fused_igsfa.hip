@@ -178,6 +178,112 @@ __global__ void __launch_bounds__((KBM == 6 ? 768 : 512), (KBM <= 4 ? 4 : KBM <=
     }
 }
 
+// Folded iGSFA layer (hg_fused.hip, igsfa_affine): y = f(x - mean) W + c is a single GEMM from the expanded
+// input fragments to the MO output tiles, and nothing needs the input fragments afterwards — so they are
+// streamed: one K-block of the node input in registers at a time (the next one, possibly the first block of
+// the next batch-tile group, already in flight), expanded under every function and multiplied into the
+// output tiles at once.  ~100 VGPRs instead of 160-185: four waves per SIMD like k_stage.  Same workgroup
+// structure and LDS image ([fi][kb][mo] fragments, biases, means, block table) as k_igsfa.
+template <int MO, int T>
+__global__ void __launch_bounds__(512, 4) k_igfold(StageParams P) {
+    extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, nw = nthr >> 6, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int node = blockIdx.x % P.n_chunks, part = blockIdx.x / P.n_chunks;   // one node per workgroup
+    float* sb = (float*)(smem + (size_t)P.node_blocks * 64);
+    int2* stab = (int2*)(sb + P.bias_floats);
+    {
+        const f32x4* src = P.afrag + (size_t)node * P.node_blocks * 64;
+        const int nvec = P.node_blocks * 64;
+        int i = tid;
+        for (; i + 7 * nthr < nvec; i += 8 * nthr) {     // 8 x 16 B in flight per thread
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[i + u * nthr];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) smem[i + u * nthr] = v[u];
+        }
+        for (; i < nvec; i += nthr) smem[i] = src[i];
+        const float* bsrc = P.bias + (size_t)node * P.bias_floats;
+        for (int k = tid; k < P.bias_floats; k += nthr) sb[k] = bsrc[k];
+        const int2* tsrc = P.kb1tab + (size_t)node * P.kb1;
+        for (int k = tid; k < P.kb1; k += nthr) stab[k] = tsrc[k];
+    }
+    __syncthreads();
+    const int kb1 = P.kb1, nf = P.nf;
+    const int nwt = P.nodes_per_wg > 0 ? min(P.nodes_per_wg, nw) : nw;
+    if (wave >= nwt) return;
+    const f32x4* w1 = smem + lane;                        // [fi][kb][mo]
+    const float* by = sb;                                 // [MO][16]
+    const float* mu = sb + MO * 16 + kb1 * 16;            // [kb][16]  (after the unused residual biases)
+    int tile[T];
+    uint32_t trow[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        tile[t] = (part * nwt + wave) * T + t;
+        trow[t] = (uint32_t)(tile[t] < P.n_tiles ? tile[t] : tile[0]) * (uint32_t)P.nb_in;
+    }
+    if (tile[0] >= P.n_tiles) return;
+    f32x4 bf[T], bfn[T];
+    int nk = __builtin_amdgcn_readfirstlane(stab[0].y);
+    {
+        const int sb0 = __builtin_amdgcn_readfirstlane(stab[0].x);
+#pragma unroll
+        for (int t = 0; t < T; ++t) bf[t] = P.in[(size_t)(trow[t] + sb0) * 64 + lane];
+    }
+    for (int grp = part; grp < P.tile_groups; grp += P.tile_parts) {
+        const int tn0 = ((grp + P.tile_parts) * nwt + wave) * T;
+        const bool has_next = grp + P.tile_parts < P.tile_groups && tn0 < P.n_tiles;
+        uint32_t trow_nx[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int tn = tn0 + t;
+            trow_nx[t] = has_next ? (uint32_t)(tn < P.n_tiles ? tn : tn0) * (uint32_t)P.nb_in : trow[t];
+        }
+        f32x4 y[MO][T];
+#pragma unroll
+        for (int mo = 0; mo < MO; ++mo) {
+            const f32x4 bb = *(const f32x4*)(by + mo * 16 + g * 4);
+#pragma unroll
+            for (int t = 0; t < T; ++t) y[mo][t] = bb;
+        }
+        for (int kb = 0; kb < kb1; ++kb) {
+            // next block of this tile group, or the first block of the next one
+            const bool in_node = kb + 1 < kb1;
+            const int2 kbn = stab[in_node ? kb + 1 : 0];
+            const int sbn = __builtin_amdgcn_readfirstlane(kbn.x), nkn = __builtin_amdgcn_readfirstlane(kbn.y);
+#pragma unroll
+            for (int t = 0; t < T; ++t) bfn[t] = P.in[(size_t)((in_node ? trow[t] : trow_nx[t]) + sbn) * 64 + lane];
+            const f32x4 m = *(const f32x4*)(mu + kb * 16 + g * 4);
+            f32x4 x0[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) x0[t] = bf[t] - m;
+            for (int fi = 0; fi < nf; ++fi) {
+                f32x4 e[T];
+                const int fk = (P.funcp >> (4 * fi)) & 15;
+                const float ex = P.expo[fi];
+#pragma unroll
+                for (int t = 0; t < T; ++t) e[t] = apply_func(fk, ex, x0[t]);
+                gemm_block<MO, T>(w1 + ((size_t)(fi * kb1 + kb) * MO) * 64, e, y, nk);
+            }
+#pragma unroll
+            for (int t = 0; t < T; ++t) bf[t] = bfn[t];
+            nk = nkn;
+        }
+#pragma unroll
+        for (int mo = 0; mo < MO; ++mo)
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+                if (tile[t] < P.n_tiles) P.out[((size_t)tile[t] * P.nb_out + (size_t)node * MO + mo) * 64 + lane] = y[mo][t];
+        if (!has_next) break;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            tile[t] = tn0 + t;
+            trow[t] = trow_nx[t];
+        }
+    }
+}
+
 template <int MS, int MO>
 static StageFn pick_igsfa_t(int T, int kb1) {
     // the input fragments of a node stay in registers through all three GEMMs: the block capacity sets the
@@ -187,6 +293,15 @@ static StageFn pick_igsfa_t(int T, int kb1) {
     if (kb1 <= 6) return T == 2 ? (StageFn)k_igsfa<MS, MO, 2, 6> : (StageFn)k_igsfa<MS, MO, 1, 6>;
     return T == 2 ? (StageFn)k_igsfa<MS, MO, 2, 8> : (StageFn)k_igsfa<MS, MO, 1, 8>;
 }
+StageFn pick_igfold(int mo, int T) {
+    switch (mo) {
+        case 1: return T == 2 ? (StageFn)k_igfold<1, 2> : (StageFn)k_igfold<1, 1>;
+        case 2: return T == 2 ? (StageFn)k_igfold<2, 2> : (StageFn)k_igfold<2, 1>;
+        case 3: return T == 2 ? (StageFn)k_igfold<3, 2> : (StageFn)k_igfold<3, 1>;
+        default: return T == 2 ? (StageFn)k_igfold<4, 2> : (StageFn)k_igfold<4, 1>;
+    }
+}
+
 StageFn pick_igsfa(int ms, int mo, int T, int kb1) {   // ms <= mo (the slow features are a prefix of the output)
     switch (ms * 10 + mo) {
         case 11: return pick_igsfa_t<1, 1>(T, kb1);
