@@ -66,7 +66,12 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / K
 one_frame_batched()
 torch.cuda.synchronize()
-assert torch.equal(torch.cat(feats), all_feats)          # same features either way, bit for bit
+# same features either way: a window's result does not depend on its batch beyond rounding (levels of a single
+# batch tile take the unfused first-layer kernels, whose accumulation order differs in the last bits)
+lvl = torch.cat(feats)
+dev_max = float((lvl - all_feats).abs().max() / all_feats.abs().max())
+assert dev_max <= 1e-5, dev_max
+print("  level-by-level vs one batch: max relative difference %.1e" % dev_max)
 t0 = time.perf_counter()
 for _ in range(K):
     one_frame_batched()
