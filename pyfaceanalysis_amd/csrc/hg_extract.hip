@@ -21,34 +21,65 @@ namespace hg { void set_last_error(const std::string& s); }
 
 namespace {
 
+// Source index tables, one entry per thread.  PIL steps the source coordinate by repeated addition
+// (o += a per output pixel); to land on the same pixel in every case each thread repeats that sum from the start
+// of its axis — O(m) dependent adds for the last entry instead of one thread walking all m entries with a
+// conversion, two compares and a store per step.
 __global__ void k_extent_tables(const double* __restrict__ boxes, int64_t n, int w, int h, int fw, int fh, int32_t* __restrict__ tabs) {
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= 2 * n) return;
-    const int64_t b = id >> 1;
-    const int axis = (int)(id & 1);
+    const int wh = w + h;
+    if (id >= n * wh) return;
+    const int64_t b = id / wh;
+    const int e = (int)(id - b * wh);
+    const int axis = e >= w ? 1 : 0, i = axis ? e - w : e;
     const double lo = boxes[b * 4 + axis], hi = boxes[b * 4 + 2 + axis];
     const int m = axis ? h : w, lim = axis ? fh : fw;
     const double a = (hi - lo) / m;
     double o = lo + a * 0.5;
-    int32_t* t = tabs + b * (w + h) + (axis ? w : 0);
-    for (int i = 0; i < m; ++i) {
-        const int v = o < 0.0 ? -1 : (int)o;
-        t[i] = (v >= 0 && v < lim) ? v : -1;
-        o += a;
-    }
+    for (int k = 0; k < i; ++k) o += a;
+    const int v = o < 0.0 ? -1 : (int)o;
+    tabs[b * wh + e] = (v >= 0 && v < lim) ? v : -1;
 }
 
+// One workgroup per (group of output rows, box): no index divisions, the row's source line and the column table are
+// read once; four output pixels per thread and one vector store when the output is uint8.
 template <typename FT, typename OT>
-__global__ void k_extent_gather(const FT* __restrict__ frame, int64_t ld, const int32_t* __restrict__ tabs, int64_t n, int w, int h,
-                                OT* __restrict__ out, int64_t ldo) {
-    const int64_t total = n * w * h;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t b = idx / (w * h);
-        const int p = (int)(idx - b * (w * h));
-        const int y = p / w, x = p - y * w;
+__global__ void __launch_bounds__(256) k_extent_gather(const FT* __restrict__ frame, int64_t ld, const int32_t* __restrict__ tabs, int64_t n,
+                                                        int w, int h, OT* __restrict__ out, int64_t ldo) {
+    const int y = blockIdx.x * blockDim.y + threadIdx.y;     // blockDim.y output rows per workgroup
+    if (y >= h) return;
+    for (int64_t b = blockIdx.y; b < n; b += gridDim.y) {
         const int32_t* t = tabs + b * (w + h);
-        const int xs = t[x], ys = t[w + y];
-        out[b * ldo + p] = (xs >= 0 && ys >= 0) ? (OT)frame[(int64_t)ys * ld + xs] : (OT)0;
+        const int ys = t[w + y];
+        const FT* src = frame + (int64_t)(ys >= 0 ? ys : 0) * ld;
+        OT* dst = out + b * ldo + (int64_t)y * w;
+        if constexpr (sizeof(OT) == 1) {
+            if ((w & 3) == 0 && (ldo & 3) == 0 && ((uintptr_t)out & 3) == 0) {
+                for (int x = threadIdx.x * 4; x < w; x += blockDim.x * 4) {
+                    uint32_t pk = 0;
+                    int xs4[4];
+                    if (((w + h) & 3) == 0) {            // table rows 16-byte aligned: one vector read
+                        const int4 v4 = *(const int4*)(t + x);
+                        xs4[0] = v4.x; xs4[1] = v4.y; xs4[2] = v4.z; xs4[3] = v4.w;
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) xs4[k] = t[x + k];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int xs = xs4[k];
+                        const uint32_t v = (xs >= 0 && ys >= 0) ? (uint32_t)(uint8_t)(OT)src[xs] : 0u;
+                        pk |= v << (8 * k);
+                    }
+                    *(uint32_t*)(dst + x) = pk;
+                }
+                continue;
+            }
+        }
+        for (int x = threadIdx.x; x < w; x += blockDim.x) {
+            const int xs = t[x];
+            dst[x] = (xs >= 0 && ys >= 0) ? (OT)src[xs] : (OT)0;
+        }
     }
 }
 
@@ -69,11 +100,13 @@ int guarded(F&& fn) {
 template <typename FT>
 void launch_gather(const void* frame, int64_t ld, const int32_t* tabs, int64_t n, int w, int h, void* out, int out_dtype, int64_t ldo,
                    hipStream_t st) {
-    const unsigned grid = (unsigned)std::min<int64_t>((n * w * h + 255) / 256, 1 << 16);
+    const unsigned tx = w >= 1024 ? 256 : w >= 256 ? 64 : 32;       // four pixels per thread on the uint8 path
+    const dim3 thr(tx, 256 / tx);
+    const dim3 grid((unsigned)((h + thr.y - 1) / thr.y), (unsigned)std::min<int64_t>(n, 65535));
     switch (out_dtype) {
-        case HG_U8: hipLaunchKernelGGL((k_extent_gather<FT, uint8_t>), grid, 256, 0, st, (const FT*)frame, ld, tabs, n, w, h, (uint8_t*)out, ldo); break;
-        case HG_F32: hipLaunchKernelGGL((k_extent_gather<FT, float>), grid, 256, 0, st, (const FT*)frame, ld, tabs, n, w, h, (float*)out, ldo); break;
-        default: hipLaunchKernelGGL((k_extent_gather<FT, double>), grid, 256, 0, st, (const FT*)frame, ld, tabs, n, w, h, (double*)out, ldo); break;
+        case HG_U8: hipLaunchKernelGGL((k_extent_gather<FT, uint8_t>), grid, thr, 0, st, (const FT*)frame, ld, tabs, n, w, h, (uint8_t*)out, ldo); break;
+        case HG_F32: hipLaunchKernelGGL((k_extent_gather<FT, float>), grid, thr, 0, st, (const FT*)frame, ld, tabs, n, w, h, (float*)out, ldo); break;
+        default: hipLaunchKernelGGL((k_extent_gather<FT, double>), grid, thr, 0, st, (const FT*)frame, ld, tabs, n, w, h, (double*)out, ldo); break;
     }
 }
 
@@ -120,7 +153,9 @@ int hg_patcher_extract_device(hg_patcher* p, const void* frame_dev, int frame_dt
         HG_HIP(hipSetDevice(p->device));
         hipStream_t st = (hipStream_t)stream;
         p->tabs.alloc((size_t)n * (out_w + out_h) * 4);
-        hipLaunchKernelGGL(k_extent_tables, (unsigned)((2 * n + 63) / 64), 64, 0, st, boxes_dev, n, out_w, out_h, frame_w, frame_h,
+        const int64_t n_ent = n * (out_w + out_h);
+        if ((n_ent + 255) / 256 > 0x7fffffffll) hg::fail(HG_ERR_ARG, "too many boxes");
+        hipLaunchKernelGGL(k_extent_tables, (unsigned)((n_ent + 255) / 256), 256, 0, st, boxes_dev, n, out_w, out_h, frame_w, frame_h,
                            (int32_t*)p->tabs.p);
         if (frame_dtype == HG_U8)
             launch_gather<uint8_t>(frame_dev, ld, (const int32_t*)p->tabs.p, n, out_w, out_h, out_dev, out_dtype, ldo, st);
