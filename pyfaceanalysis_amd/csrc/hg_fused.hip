@@ -349,7 +349,9 @@ bool build_stages(const TNode& root, std::vector<FStage>& stages, std::string& w
 // weights of `nodes_per_group` nodes at a time are copied once into LDS and shared by all waves
 // (A fragments by ds_read_b128); activation fragments come straight from HBM/L2 with one 16 B/lane
 // coalesced load per K-block and tile, prefetched one K-block ahead.
-template <int MT1, int MT2, int T, bool STAMP = false>
+// REM: the last tile of both affines holds <= 4 real rows and its A fragments are stored in 4x4 form
+// (hg_fused_dev.hpp, "Remainder tiles").
+template <int MT1, int MT2, int T, bool STAMP = false, bool REM = false>
 __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
     extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
     const int tid = threadIdx.x, nthr = blockDim.x;
@@ -440,6 +442,9 @@ __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
 #pragma unroll
                     for (int t = 0; t < T; ++t) z[mt][t] = bb;
                 }
+                f32x4 d4[T];      // REM: 4x4-form accumulators of the last z tile
+#pragma unroll
+                for (int t = 0; t < T; ++t) d4[t] = f32x4{0.f, 0.f, 0.f, 0.f};
                 unsigned long long ts0 = 0, ts1 = 0;
                 if (STAMP) ts0 = stamp_now();
                 for (int kbi = 0; kbi < P.kb1; ++kbi) {
@@ -450,13 +455,18 @@ __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
                     const int nkn = __builtin_amdgcn_readfirstlane(kbn.y);
 #pragma unroll
                     for (int t = 0; t < T; ++t) bfn[t] = P.in[(size_t)((in_group ? trow[t] : trow_nx[t]) + sbn) * 64 + lane];
-                    gemm_block<MT1, T>(wA1 + kbi * MT1 * 64, bf, z, nk);
+                    if constexpr (REM) gemm_block_rem<MT1, T>(wA1 + kbi * MT1 * 64, bf, z, d4, nk);
+                    else gemm_block<MT1, T>(wA1 + kbi * MT1 * 64, bf, z, nk);
 #pragma unroll
                     for (int t = 0; t < T; ++t) bf[t] = bfn[t];
                     nk = nkn;
                 }
+                if constexpr (REM) {
+#pragma unroll
+                    for (int t = 0; t < T; ++t) z[MT1 - 1][t] += rem4_rows(d4[t], g);
+                }
                 if (STAMP) ts1 = stamp_now();
-                node_tail<MT1, MT2, T>(P, wA2, b1 + MT1 * 16, (g0 + ln) * P.mto, z, tile, lane);
+                node_tail<MT1, MT2, T, REM>(P, wA2, b1 + MT1 * 16, (g0 + ln) * P.mto, z, tile, lane);
                 if (STAMP) {
                     unsigned long long ts2 = stamp_now();
                     t_g1 += ts1 - ts0;
@@ -616,7 +626,11 @@ StageFn pick_stage_m2(int mt2, int T) {
         default: return pick_stage_t<MT1, 4>(T);
     }
 }
-StageFn pick_stage(int mt1, int mt2, int T) {
+StageFn pick_stage(int mt1, int mt2, int T, bool rem = false) {
+    if (rem) {      // instantiated where the synthetic and test networks need it (plan time checks the same list)
+        if (mt1 == 3 && mt2 == 3) return T == 2 ? (StageFn)k_stage<3, 3, 2, false, true> : (StageFn)k_stage<3, 3, 1, false, true>;
+        if (mt1 == 2 && mt2 == 2) return T == 2 ? (StageFn)k_stage<2, 2, 2, false, true> : (StageFn)k_stage<2, 2, 1, false, true>;
+    }
     switch (mt1) {
         case 1: return pick_stage_m2<1>(mt2, T);
         case 2: return pick_stage_m2<2>(mt2, T);
@@ -636,6 +650,7 @@ struct HostStage {
     int mt1 = 1, mt2 = 1, mto = 1, nb_out = 0, nb_in = 0, n_nodes = 0, kb1 = 0, nf = 0;
     int node_blocks = 0, bias_floats = 0, nk_last = 4;
     int p_max = 0, s_max = 0;   // widest first / second affine of the layer (real outputs)
+    bool rem4 = false;          // last tiles of both affines in 4x4 form (k_stage REM instantiations)
     bool has_exp = false, contig4 = false, vec_ok = false;
     std::vector<ExpFunc> funcs;
     uint8_t nk2[kMaxMT][kMaxFuncs] = {};
@@ -841,6 +856,32 @@ public:
                     cur_q.push_back(f % 16);
                 }
             }
+            // Remainder tiles (hg_fused_dev.hpp): when the last tile of BOTH affines holds 1..4 real rows, store its
+            // A fragments in 4x4 form for the k_stage REM instantiations.  Only stages that always run on
+            // k_stage: not the first two (front kernels read the ordinary form) and more than 4 nodes
+            // (k_stage_splitm takes the small ones).
+            {
+                const int r1 = hs.p_max - 16 * (hs.mt1 - 1), r2 = hs.s_max - 16 * (hs.mt2 - 1);
+                hs.rem4 = si >= 2 && hs.has_exp && n > 4 && hs.mt1 == hs.mt2 && (hs.mt1 == 2 || hs.mt1 == 3) && r1 >= 1 && r1 <= 4 &&
+                          r2 >= 1 && r2 <= 4 && !getenv("HIGSFA_NO_REM4");
+                if (hs.rem4) {
+                    auto to4x4 = [](float* blk) {
+                        float old[256];
+                        std::copy(blk, blk + 256, old);
+                        for (int l = 0; l < 64; ++l) {
+                            const int src = (l & 48) | ((l & 3) << 2);
+                            for (int r = 0; r < 4; ++r) blk[l * 4 + r] = old[src * 4 + r];
+                        }
+                    };
+                    for (int ni = 0; ni < n; ++ni) {
+                        float* wnode = hs.afrag.data() + (size_t)ni * hs.node_blocks * 256;
+                        for (int kb = 0; kb < hs.kb1; ++kb) to4x4(wnode + ((size_t)kb * hs.mt1 + hs.mt1 - 1) * 256);
+                        float* w2 = wnode + (size_t)hs.kb1 * hs.mt1 * 256;
+                        for (int b2 = 0; b2 < hs.mt1 * hs.nf; ++b2) to4x4(w2 + ((size_t)b2 * hs.mt2 + hs.mt2 - 1) * 256);
+                    }
+                    // the 4x4 tiles cost a quarter of the MFMA time of a 16x16 tile
+                }
+            }
             hs.nb_out = n * hs.mto;
             prev_blk.swap(cur_blk);
             prev_q.swap(cur_q);
@@ -848,7 +889,7 @@ public:
             max_nb_ = std::max(max_nb_, hs.nb_out);
             padded_flops_ += hs.mfma_per_tile * 2048 / 16;
             std::ostringstream os;
-            os << "fused stage " << si << ": " << hs.n_nodes << " nodes, K-blocks " << hs.kb1 << ", tiles " << hs.mt1 << "x" << hs.mt2
+            os << "fused stage " << si << (hs.rem4 ? " (4x4 remainder tiles)" : "") << ": " << hs.n_nodes << " nodes, K-blocks " << hs.kb1 << ", tiles " << hs.mt1 << "x" << hs.mt2
                << ", " << hs.mfma_per_tile << " MFMA/tile, " << hs.afrag.size() * 4 / 1024 << " KiB weights, out " << hs.nb_out
                << " blocks/tile";
             hs.name = os.str();
@@ -1171,7 +1212,7 @@ public:
                 // cost(P) = rounds of resident workgroups x (weight copy + tile iterations per workgroup)
                 const int64_t g8 = (int64_t)(n_groups + 7) / 8 * 8;
                 size_t lds_probe = (size_t)npg * s.node_blocks * 1024 + (size_t)npg * s.bias_floats * 4 + (size_t)npg * s.kb1 * 8;
-                const double capacity = 256.0 * resident_blocks(pick_stage(s.mt1, s.mt2, T), nw * 64, lds_probe);
+                const double capacity = 256.0 * resident_blocks(pick_stage(s.mt1, s.mt2, T, s.rem4), nw * 64, lds_probe);
                 int tile_parts = 1;
                 double best = 1e300;
                 for (int pp = 1; pp <= tile_groups; ++pp) {
@@ -1190,9 +1231,9 @@ public:
                 const int64_t blocks = (int64_t)((P.n_chunks + 7) / 8) * 8 * tile_parts;
                 if (blocks > 0x7fffffffll) fail(HG_ERR_ARG, "batch too large");
                 size_t lds_bytes = (size_t)npg * s.node_blocks * 1024 + (size_t)npg * s.bias_floats * 4 + (size_t)npg * s.kb1 * 8;
-                StageFn fn = pick_stage(s.mt1, s.mt2, T);
+                StageFn fn = pick_stage(s.mt1, s.mt2, T, s.rem4);
                 const char* stamp_env = getenv("HIGSFA_STAMP");
-                if (stamp_env && atoi(stamp_env) == (int)si && s.mt1 == s.mt2 && (s.mt1 == 4 || s.mt1 == 3) && T == 2) {
+                if (stamp_env && atoi(stamp_env) == (int)si && s.mt1 == s.mt2 && (s.mt1 == 4 || s.mt1 == 3) && T == 2 && !s.rem4) {
                     // diagnostic instantiation with s_memtime stamps (never used in timed runs)
                     fn = s.mt1 == 4 ? (StageFn)k_stage<4, 4, 2, true> : (StageFn)k_stage<3, 3, 2, true>;
                     stamp_buf_.alloc((size_t)blocks * 8 * 6 * 8);

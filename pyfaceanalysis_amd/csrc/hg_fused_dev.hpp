@@ -115,10 +115,49 @@ __device__ __forceinline__ void gemm_block(WP wp, const f32x4 (&b)[T], f32x4 (&a
     }
 }
 
+// Remainder tiles.  When an affine has 16 m + (1..4) outputs its last 16-row tile holds at most four real rows
+// (features 16 m + i sit at rows 4 i = lane group g, register 0).  Such a tile runs on
+// v_mfma_f32_4x4x1_16B_f32 instead — 16 independent 4x4 blocks per instruction, 8 cycles instead of 32:
+// block b = lane / 4 takes the k index g = lane / 16 of the k-step and sub-images 4 (b % 4) .. + 3, so the B
+// operand is the very same register as for the 16x16 form; the A fragment is stored in "4x4 form" (lane
+// (g, i = lane % 4) holds row 4 i of lane group g of the ordinary fragment — permuted on the host for the
+// LDS-resident weights, with ds_bpermute for the register-resident ones); the four k partial sums (lane
+// groups) are added with two cross-lane steps and lane group g keeps row g.  Same products, 3/4 of the
+// padding multiplications of those tiles gone.
+#define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ f32x4 rem4_rows(f32x4 d, int g) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        d[i] += __shfl_xor(d[i], 16);
+        d[i] += __shfl_xor(d[i], 32);
+    }
+    const float v = g == 0 ? d[0] : g == 1 ? d[1] : g == 2 ? d[2] : d[3];
+    return f32x4{v, 0.f, 0.f, 0.f};
+}
+
+// gemm_block with the last m-tile in 4x4 form: tiles 0 .. MT-2 accumulate in acc, the last one in d4.
+template <int MT, int T, typename WP>
+__device__ __forceinline__ void gemm_block_rem(WP wp, const f32x4 (&b)[T], f32x4 (&acc)[MT][T], f32x4 (&d4)[T], int nk) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const f32x4 a = wp[mt * 64];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (r < nk) {
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    if (mt < MT - 1) acc[mt][t] = MFMA16(a[r], b[t][r], acc[mt][t]);
+                    else d4[t] = MFMA4(a[r], b[t][r], d4[t]);
+                }
+            }
+    }
+}
+
 // Second half of a node: expansion of the z accumulators in registers, second affine, store.
 // wA2 / b2 point at this node's A2 fragments (+lane) and bias-2 fragment; address space (LDS or
 // global) is resolved after inlining.
-template <int MT1, int MT2, int T, typename WP, typename BP>
+template <int MT1, int MT2, int T, bool REM = false, typename WP, typename BP>
 __device__ __forceinline__ void node_tail(const StageParams& P, WP wA2, BP b2, int out_blk, f32x4 (&z)[MT1][T],
                                           const int (&tile)[T], int lane) {
     const int g = lane >> 4;
@@ -140,6 +179,9 @@ __device__ __forceinline__ void node_tail(const StageParams& P, WP wA2, BP b2, i
     const float ex0 = P.expo[0], ex1 = P.expo[1], ex2 = P.expo[2], ex3 = P.expo[3];
     const uint32_t funcp = P.funcp;
     const int nf = P.nf;
+    f32x4 d4[T];      // REM: 4x4-form accumulators of the last output tile
+#pragma unroll
+    for (int t = 0; t < T; ++t) d4[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int mt1 = 0; mt1 < MT1; ++mt1) {
         const uint32_t nkp = P.nk2p[mt1];
@@ -151,8 +193,13 @@ __device__ __forceinline__ void node_tail(const StageParams& P, WP wA2, BP b2, i
             const float ex = fi == 0 ? ex0 : (fi == 1 ? ex1 : (fi == 2 ? ex2 : ex3));
 #pragma unroll
             for (int t = 0; t < T; ++t) e[t] = apply_func(fk, ex, z[mt1][t]);
-            gemm_block<MT2, T>(wA2 + (mt1 * nf + fi) * MT2 * 64, e, y, nk);
+            if constexpr (REM) gemm_block_rem<MT2, T>(wA2 + (mt1 * nf + fi) * MT2 * 64, e, y, d4, nk);
+            else gemm_block<MT2, T>(wA2 + (mt1 * nf + fi) * MT2 * 64, e, y, nk);
         }
+    }
+    if constexpr (REM) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) y[MT2 - 1][t] += rem4_rows(d4[t], g);
     }
 #pragma unroll
     for (int mt = 0; mt < MT2; ++mt)

@@ -235,25 +235,8 @@ __global__ void __launch_bounds__(512) k_stage0p(StageParams P) {
 // layer-0 activation (64 KiB per sub-image written and read back) never exists in memory.
 // Requirements checked on the host: layer 0 as for k_stage0p; layer-1 node n reads exactly the
 // blocks of layer-0 nodes 2n and 2n+1; both layer-1 affines have <= 32 outputs; same <= 2 functions.
-// REM4: both layer-1 affines have 17..20 outputs, i.e. their second 16-row tile holds only four real rows
-// (features 16..19 sit at rows 0, 4, 8, 12 = lane group g, register 0).  Those tiles run on
-// v_mfma_f32_4x4x1_16B_f32 instead — 16 independent 4x4 blocks per instruction, 8 cycles instead of 32:
-// block b = lane / 4 takes k index g = lane / 16 of the k-step and sub-images 4 (b % 4) .. + 3, so the B
-// operand is the very same register as for the 16x16 form; A lane (g, i) holds W[row i][k]; the four k
-// partial sums (lane groups) are added with two cross-lane steps and lane group g keeps row g.
-// Same products, 3/4 of the padding multiplications of those tiles gone (22 % of this kernel's MFMA time).
-#define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 0, 0, 0)
-
-__device__ __forceinline__ f32x4 rem4_rows(f32x4 d, int g) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        d[i] += __shfl_xor(d[i], 16);
-        d[i] += __shfl_xor(d[i], 32);
-    }
-    const float v = g == 0 ? d[0] : g == 1 ? d[1] : g == 2 ? d[2] : d[3];
-    return f32x4{v, 0.f, 0.f, 0.f};
-}
-
+// REM4: both layer-1 affines have 17..20 outputs, i.e. their second 16-row tile holds only four real rows:
+// those tiles run in the 4x4 MFMA form (hg_fused_dev.hpp, "Remainder tiles"; 22 % of this kernel's MFMA time).
 template <typename XT, bool STAMP = false, bool REM4 = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 3))) k_stage01p(StageParams P, StageParams Q) {
     extern __shared__ __attribute__((aligned(16))) f32x4 smem[];

@@ -172,3 +172,23 @@ def fuzz_igsfa_net(seed):
         if w * h == 1:
             break
     return flow
+
+
+def remainder_net(seed=0):
+    """32x32 input, four layers; layers 2 and 3 have 17..20 and 33..36 outputs per affine with more than four
+    nodes, i.e. they take the 4x4-MFMA remainder-tile instantiations of k_stage (2x2 and 3x3 tiles)."""
+    rng = np.random.default_rng(seed)
+    funcs = [N.identity, N.unsigned_08expo]
+
+    def layer(n, d_in, p, s):
+        out = []
+        for _ in range(n):
+            ex = N.GeneralExpansionNode(funcs, p)
+            out.append(N.FlowNode([rand_pca(rng, d_in, p, N.WhiteningNode), ex, rand_sfa(rng, ex.output_dim, s)]))
+        return N.Layer(out)
+
+    sb0 = N.Rectangular2dSwitchboard((32, 32), (4, 4), (4, 4), 1)      # 64 nodes
+    sb1 = N.Rectangular2dSwitchboard((8, 8), (2, 1), (2, 1), 9)        # 32 nodes of 18 inputs
+    sb2 = N.Rectangular2dSwitchboard((4, 8), (1, 2), (1, 2), 12)       # 16 nodes of 24 inputs
+    sb3 = N.Rectangular2dSwitchboard((4, 4), (2, 1), (2, 1), 18)       # 8 nodes of 36 inputs
+    return [sb0, layer(64, 16, 10, 9), sb1, layer(32, 18, 14, 12), sb2, layer(16, 24, 19, 18), sb3, layer(8, 36, 35, 34)]

@@ -80,6 +80,26 @@ def test_fuzzed_hierarchies(native_lib, seed):
         flow.close()
 
 
+@pytest.mark.parametrize("n", [5, 300])
+def test_remainder_tiles(native_lib, n, monkeypatch):
+    """Layers whose affines end in a tile of <= 4 real rows (helpers.remainder_net): the 4x4-MFMA form of k_stage
+    (one / two batch tiles per wave) against the oracle, and against the ordinary form (HIGSFA_NO_REM4)."""
+    nodes = helpers.remainder_net(3)
+    x = np.random.default_rng(n).normal(size=(n, nodes[0].input_dim)) * 1.5
+    ref = oracle.execute_flow(nodes, x)
+    flow = Flow(nodes)
+    desc = flow.describe()
+    assert desc.count("(4x4 remainder tiles)") == 2
+    y = flow.execute(x)
+    assert rel_err(y, ref) <= TOL
+    flow.close()
+    monkeypatch.setenv("HIGSFA_NO_REM4", "1")
+    flow = Flow(nodes)
+    assert "(4x4 remainder tiles)" not in flow.describe()
+    assert rel_err(flow.execute(x), ref) <= TOL
+    flow.close()
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_fuzzed_igsfa_hierarchies(native_lib, seed, monkeypatch):
     """Random iGSFA hierarchies (helpers.fuzz_igsfa_net) against the oracle.  Nodes of up to 64 inputs are folded
