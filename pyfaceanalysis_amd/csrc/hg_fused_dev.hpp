@@ -26,9 +26,9 @@ struct DRun {
     int32_t start, len, lds_off, pad;
 };
 
-// k_stage01p: two LDS tiles (one barrier per tile group, 2 workgroups per CU) or one (two barriers, but a
-// third workgroup per CU fits in LDS)
-constexpr bool kDoubleBuffer01 = false;
+// k_stage01p: two LDS tiles (one barrier per tile group) or one (two barriers, half the LDS).  With the packed
+// tile layout (128 + 4 words per row) both fit three workgroups per CU and measure the same (152-154 us).
+constexpr bool kDoubleBuffer01 = true;
 
 struct StageParams {
     const f32x4* afrag;   // [node][ A1: kb1 x MT1 | A2: MT1 x nf x MT2 ] blocks of 64 x f32x4
