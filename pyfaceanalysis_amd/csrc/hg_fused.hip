@@ -1031,6 +1031,15 @@ public:
                 if (ev) HG_HIP(hipEventRecord(ev[e++], st));
                 continue;
             }
+            if (s.kind == 2 && s.ig_folded && s.n_nodes <= 8 && s.nf <= 2 && s.kb1 <= 8 && (int64_t)s.n_nodes * n_tiles <= 16384 &&
+                !getenv("HIGSFA_IG_RESIDENT")) {
+                // top of an iGSFA hierarchy: one node and two tiles per small workgroup, output tiles split over waves
+                P.ig_folded = 1;
+                launch_igfold_split(P, s.mt2, n_tiles, st);
+                std::swap(cur, nxt);
+                if (ev) HG_HIP(hipEventRecord(ev[e++], st));
+                continue;
+            }
             if (s.kind == 2) {        // iGSFA layer
                 // Waves that take tiles (nwt) x tiles per wave (T): the largest shape that still gives every CU
                 // a workgroup (the top layers have 16 .. 1 nodes: with 8 x 2 a single node would run on 16 CUs).

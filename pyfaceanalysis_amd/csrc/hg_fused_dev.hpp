@@ -217,7 +217,8 @@ StageFn pick_stage0(int mt1, int mt2, int T, int x_dtype);            // hg_fuse
 StageFn pick_stage0p(int x_dtype);
 StageFn2 pick_stage01p(int x_dtype, bool stamp, bool rem4);
 StageFn pick_igsfa(int ms, int mo, int T, int kb1);                   // hg_fused_igsfa.hip
-StageFn pick_igfold(int mo, int T);                                                          // hg_fused_igsfa.hip
+StageFn pick_igfold(int mo, int T);
+void launch_igfold_split(const StageParams& P, int mo, int n_tiles, hipStream_t st);                                                          // hg_fused_igsfa.hip
 void launch_im2frag(const void* x, int x_dtype, int64_t ldx, int64_t n_rows, int n_tiles, int nb, const int32_t* gcol, f32x4* out,
                     int vec4, hipStream_t st);
 

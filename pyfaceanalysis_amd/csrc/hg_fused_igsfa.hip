@@ -293,6 +293,85 @@ static StageFn pick_igsfa_t(int T, int kb1) {
     if (kb1 <= 6) return T == 2 ? (StageFn)k_igsfa<MS, MO, 2, 6> : (StageFn)k_igsfa<MS, MO, 1, 6>;
     return T == 2 ? (StageFn)k_igsfa<MS, MO, 2, 8> : (StageFn)k_igsfa<MS, MO, 1, 8>;
 }
+// Folded iGSFA layers with FEW nodes (the top of the hierarchy): not enough (node, tile) pairs to fill the
+// chip with whole nodes, and copying a node's 64 KiB of weights into LDS per workgroup is all latency.  Like
+// k_stage_splitm: a workgroup shares ONE node and T batch tiles; wave w < kb1 loads input block w, subtracts
+// the mean and writes the expanded fragments to LDS; after one barrier wave w < MO computes output tile w
+// from all of them, its A fragments straight from L2 (each read by exactly one wave of the workgroup, all
+// requested before the barrier).  nf <= 2, kb1 <= 8.
+template <int T>
+__global__ void __launch_bounds__(512) k_igfold_split(StageParams P, int mo_n) {
+    extern __shared__ __attribute__((aligned(16))) f32x4 smem[];      // [fi][kb][t][64]
+    const int lane = threadIdx.x & 63, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int node = blockIdx.x % P.n_nodes, grp = blockIdx.x / P.n_nodes;
+    const int kb1 = P.kb1, nf = P.nf;
+    int tile[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) tile[t] = grp * T + t;
+    const f32x4* wnode = P.afrag + (size_t)node * P.node_blocks * 64 + lane;      // [fi][kb][mo]
+    const float* bnode = P.bias + (size_t)node * P.bias_floats;                    // [MO][16] | [kb][16] unused | [kb][16] means
+    const int2* kt = P.kb1tab + (size_t)node * kb1;
+    // output-tile weights: 2 x 8 fragments at most, requested before anything waits
+    f32x4 a[2][8];
+    if (w < mo_n) {
+#pragma unroll
+        for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb)
+                if (fi < nf && kb < kb1) a[fi][kb] = wnode[((size_t)(fi * kb1 + kb) * mo_n + w) * 64];
+    }
+    if (w < kb1) {
+        const int2 e = kt[w];
+        const f32x4 m = *(const f32x4*)(bnode + mo_n * 16 + kb1 * 16 + w * 16 + g * 4);
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int tl = tile[t] < P.n_tiles ? tile[t] : tile[0];
+            const f32x4 x0 = P.in[((size_t)tl * P.nb_in + e.x) * 64 + lane] - m;
+            for (int fi = 0; fi < nf; ++fi)
+                smem[((fi * kb1 + w) * T + t) * 64 + lane] = apply_func((P.funcp >> (4 * fi)) & 15, P.expo[fi], x0);
+        }
+    }
+    __syncthreads();
+    if (w >= mo_n) return;
+    f32x4 y[T];
+    {
+        const f32x4 bb = *(const f32x4*)(bnode + w * 16 + g * 4);
+#pragma unroll
+        for (int t = 0; t < T; ++t) y[t] = bb;
+    }
+#pragma unroll
+    for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) {
+            if (fi >= nf || kb >= kb1) continue;
+            const int nk = kt[kb].y;
+            f32x4 e[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) e[t] = smem[((fi * kb1 + kb) * T + t) * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (r < nk) {
+#pragma unroll
+                    for (int t = 0; t < T; ++t) y[t] = MFMA16(a[fi][kb][r], e[t][r], y[t]);
+                }
+        }
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+        if (tile[t] < P.n_tiles) P.out[((size_t)tile[t] * P.nb_out + (size_t)node * mo_n + w) * 64 + lane] = y[t];
+}
+
+void launch_igfold_split(const StageParams& P, int mo, int n_tiles, hipStream_t st) {
+    const int T = n_tiles >= 2 ? 2 : 1;
+    const int groups = (n_tiles + T - 1) / T;
+    const int nwv = P.kb1 > mo ? P.kb1 : mo;
+    const size_t lds = (size_t)P.nf * P.kb1 * T * 1024;
+    if (T == 2)
+        hipLaunchKernelGGL(k_igfold_split<2>, (unsigned)(groups * P.n_nodes), nwv * 64, lds, st, P, mo);
+    else
+        hipLaunchKernelGGL(k_igfold_split<1>, (unsigned)(groups * P.n_nodes), nwv * 64, lds, st, P, mo);
+}
+
 StageFn pick_igfold(int mo, int T) {
     switch (mo) {
         case 1: return T == 2 ? (StageFn)k_igfold<1, 2> : (StageFn)k_igfold<1, 1>;
