@@ -80,6 +80,25 @@ def test_fuzzed_hierarchies(native_lib, seed):
         flow.close()
 
 
+@pytest.mark.parametrize("kw", [{}, {"node_kind": "igsfa"}])
+def test_non_finite_rows_stay_in_their_row(native_lib, nets, kw):
+    """A NaN / Inf pixel poisons only its own sub-image (rows are independent): the other rows are
+    bit-identical to a clean run, the poisoned rows come back non-finite, nothing crashes."""
+    nodes = nets("T5L-16", **kw)
+    x = synth.make_subimages(40, 16, dtype=np.float64)
+    flow = Flow(nodes)
+    clean = flow.execute(x)
+    bad = x.copy()
+    bad[3, 17] = np.nan
+    bad[21, 200] = np.inf
+    y = flow.execute(bad)
+    keep = np.ones(40, dtype=bool)
+    keep[[3, 21]] = False
+    assert np.array_equal(y[keep], clean[keep])
+    assert not np.isfinite(y[3]).all() and not np.isfinite(y[21]).all()
+    flow.close()
+
+
 @pytest.mark.parametrize("n", [5, 300])
 def test_remainder_tiles(native_lib, n, monkeypatch):
     """Layers whose affines end in a tile of <= 4 real rows (helpers.remainder_net): the 4x4-MFMA form of k_stage
