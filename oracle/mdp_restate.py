@@ -80,12 +80,20 @@ def exec_expansion(node, x):
 
 def exec_igsfa(node, x):
     """cuicuilco.igsfa_node.iGSFANode._execute (IEVMLRecNode in older pickles,
-    face_analysis.py:463-467; alias FaceDetectUpdated.py:64); SURVEY.md §8a row a8."""
+    face_analysis.py:463-467; alias FaceDetectUpdated.py:64); SURVEY.md §8a row a8.
+    The two points on which public descriptions of cuicuilco differ are read from explicit fields of
+    the node: ``scaling`` (per-column ``magn_n_sfa_x`` or a matrix) and ``lr_input`` (does the linear
+    reconstruction read the scaled or the normalised slow features)."""
     x0 = x - node.x_mean
     e = execute_node(node.exp_node, x0) if node.exp_node is not None else x0
-    s = execute_node(node.sfa_node, e) * node.magn_n_sfa_x
+    n_sfa = execute_node(node.sfa_node, e)
+    if getattr(node, "scaling", "per_column") == "matrix":
+        s = np.dot(n_sfa, node.scaling_matrix)
+    else:
+        s = n_sfa * node.magn_n_sfa_x
     if node.reconstruct_with_sfa and node.lr_node is not None:
-        r = x0 - execute_node(node.lr_node, s)
+        lr_in = n_sfa if getattr(node, "lr_input", "scaled") == "unscaled" else s
+        r = x0 - execute_node(node.lr_node, lr_in)
     else:
         r = x0
     q = execute_node(node.pca_node, r)

@@ -66,8 +66,14 @@ def execute_node(node, x):
     if "iGSFANode" in names:
         x0 = x - node.x_mean
         e = execute_node(node.exp_node, x0) if node.exp_node is not None else x0
-        s = execute_node(node.sfa_node, e) * node.magn_n_sfa_x
-        r = x0 - execute_node(node.lr_node, s) if node.lr_node is not None else x0
+        nsf = execute_node(node.sfa_node, e)
+        if getattr(node, "scaling", "per_column") == "matrix":       # s = n @ M through the C affine (a = 0, b = 0)
+            k = nsf.shape[1]
+            s = _affine(nsf, np.zeros(k), node.scaling_matrix, np.zeros(k))
+        else:
+            s = nsf * node.magn_n_sfa_x
+        lr_in = nsf if getattr(node, "lr_input", "scaled") == "unscaled" else s
+        r = x0 - execute_node(node.lr_node, lr_in) if node.lr_node is not None else x0
         q = execute_node(node.pca_node, r)
         return np.concatenate([s[:, :node.num_sfa_features_preserved], q], axis=1)
     if "PCANode" in names:

@@ -13,8 +13,11 @@ back (round-trip tests, tools).  Every record and every array starts 8-byte alig
              5 AFFINE(aux=subtype; f64 a[in], f64 W[in*out] row-major, f64 b[out])
                                                y = (x - a) @ W + b
              6 EXPANSION(aux=n; n x {u32 kind,u32 sel,u32 k,u32 0,f64 expo})
-             7 IGSFA(aux=num_sfa_features_preserved; u32 has_exp,u32 has_lr; f64 x_mean[in];
-                     [EXPANSION]; AFFINE sfa; f64 magn[sfa.out]; [AFFINE lr]; AFFINE pca)
+             7 IGSFA(aux=num_sfa_features_preserved; u32 has_exp,u32 flags; f64 x_mean[in];
+                     [EXPANSION]; AFFINE sfa; f64 magn[sfa.out] or f64 M[sfa.out^2]; [AFFINE lr]; AFFINE pca)
+                     flags: bit0 lr_node present; bit1 lr_node reads the UNSCALED slow features
+                     (lr_input="unscaled"); bit2 scaling is a matrix M (s = n @ M, row-major) instead
+                     of a per-column scale
              8 IDENTITY   9 HEAD   10 CUTOFF(f64 lo, f64 hi)   11 FLOWNODE(aux=n; n nodes)
 """
 from __future__ import annotations
@@ -32,6 +35,7 @@ K_FLOW, K_SWITCHBOARD, K_LAYER, K_CLONELAYER, K_AFFINE, K_EXPANSION = 1, 2, 3, 4
 K_IGSFA, K_IDENTITY, K_HEAD, K_CUTOFF, K_FLOWNODE = 7, 8, 9, 10, 11
 
 AFF_GENERIC, AFF_PCA, AFF_WHITENING, AFF_SFA, AFF_GSFA, AFF_LINREG = 0, 1, 2, 3, 4, 5
+IG_HAS_LR, IG_LR_UNSCALED, IG_SCALE_MATRIX = 1, 2, 4
 _EXP_KIND = {"identity": 0, "abs_pow": 1, "signed_pow": 2, "quadratic": 3, "pair_adj": 4}
 _EXP_NAME = {v: k for k, v in _EXP_KIND.items()}
 
@@ -105,13 +109,17 @@ def _write_node(w, node):
             w.raw(struct.pack("<IIIId", _EXP_KIND[f.kind], f.sel, f.k, 0, f.expo))
     elif isinstance(node, N.iGSFANode):
         w.head(K_IGSFA, i, o, node.num_sfa_features_preserved)
-        w.raw(struct.pack("<II", 1 if node.exp_node is not None else 0,
-                          1 if node.lr_node is not None else 0))
+        flags = (IG_HAS_LR if node.lr_node is not None else 0) | (IG_LR_UNSCALED if node.lr_input == "unscaled" else 0) \
+            | (IG_SCALE_MATRIX if node.scaling == "matrix" else 0)
+        w.raw(struct.pack("<II", 1 if node.exp_node is not None else 0, flags))
         w.f64(node.x_mean, i)
         if node.exp_node is not None:
             _write_node(w, node.exp_node)
         _write_node(w, node.sfa_node)
-        w.f64(node.magn_n_sfa_x, node.sfa_node.output_dim)
+        if node.scaling == "matrix":
+            w.f64(node.scaling_matrix, node.sfa_node.output_dim ** 2)
+        else:
+            w.f64(node.magn_n_sfa_x, node.sfa_node.output_dim)
         if node.lr_node is not None:
             _write_node(w, node.lr_node)
         _write_node(w, node.pca_node)
@@ -195,15 +203,20 @@ def _read_node(r):
             funcs.append(N.ExpFunc(_EXP_NAME[k], expo=expo, k=kk, sel=sel))
         return N.GeneralExpansionNode(funcs, i)
     if kind == K_IGSFA:
-        has_exp, has_lr = struct.unpack("<II", r.take(8))
+        has_exp, flags = struct.unpack("<II", r.take(8))
+        if flags & ~(IG_HAS_LR | IG_LR_UNSCALED | IG_SCALE_MATRIX):
+            raise ValueError("blob: unknown iGSFA flags 0x%x" % flags)
         x_mean = r.f64(i)
         exp_node = _read_node(r) if has_exp else None
         sfa = _read_node(r)
-        magn = r.f64(sfa.output_dim)
-        lr = _read_node(r) if has_lr else None
+        k = sfa.output_dim
+        matrix = r.f64(k * k).reshape(k, k) if flags & IG_SCALE_MATRIX else None
+        magn = None if flags & IG_SCALE_MATRIX else r.f64(k)
+        lr = _read_node(r) if flags & IG_HAS_LR else None
         pca = _read_node(r)
-        return N.iGSFANode(x_mean, exp_node, sfa, magn, lr, pca, aux,
-                           reconstruct_with_sfa=bool(has_lr))
+        return N.iGSFANode(x_mean, exp_node, sfa, magn, lr, pca, aux, reconstruct_with_sfa=bool(flags & IG_HAS_LR),
+                           lr_input="unscaled" if flags & IG_LR_UNSCALED else "scaled",
+                           scaling="matrix" if flags & IG_SCALE_MATRIX else "per_column", scaling_matrix=matrix)
     if kind == K_IDENTITY:
         return N.IdentityNode(i)
     if kind == K_HEAD:

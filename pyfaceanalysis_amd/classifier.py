@@ -92,14 +92,31 @@ class _Stub(object):
         self.__dict__.update(st if isinstance(st, dict) else {"_state": st})
 
 
+# The ONLY globals the stub reader resolves to real objects: what numpy arrays / scalars and plain containers
+# need to be rebuilt.  Everything else — mdp.*, cuicuilco modules, the aliases of FaceDetectUpdated.py:57-68,
+# but also builtins such as eval / getattr / __import__ and any other numpy helper — becomes an inert
+# attribute bag, so reading a third-party .pckl executes no code of its choosing.
+_SAFE_GLOBALS = {
+    ("numpy.core.multiarray", "_reconstruct"), ("numpy.core.multiarray", "scalar"),
+    ("numpy._core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "scalar"),
+    ("numpy", "ndarray"), ("numpy", "dtype"),
+    ("copyreg", "_reconstructor"), ("_codecs", "encode"), ("collections", "OrderedDict"),
+}
+_SAFE_GLOBALS |= {("builtins", n) for n in ("object", "list", "dict", "tuple", "set", "frozenset", "int", "float", "complex",
+                                             "str", "bytes", "bytearray", "slice", "bool")}
+_PY2_MODULES = {"__builtin__": "builtins", "copy_reg": "copyreg"}
+_PY2_NAMES = {("builtins", "long"): "int", ("builtins", "unicode"): "str"}
+
+
 class StubUnpickler(pickle.Unpickler):
-    """Resolves numpy/builtin globals normally and every other global (mdp.*, cuicuilco modules,
-    aliases of FaceDetectUpdated.py:57-68) to an attribute-bag class carrying module and name."""
+    """Resolves the allowlisted numpy / builtin globals normally and every other global to an attribute-bag
+    class carrying its module and name."""
 
     def find_class(self, module, name):
-        if module.startswith("numpy") or module in ("__builtin__", "builtins", "copy_reg", "copyreg", "_codecs", "collections"):
-            module = {"__builtin__": "builtins", "copy_reg": "copyreg"}.get(module, module)
-            return super(StubUnpickler, self).find_class(module, name)
+        mod = _PY2_MODULES.get(module, module)
+        nm = _PY2_NAMES.get((mod, name), name)
+        if (mod, nm) in _SAFE_GLOBALS:
+            return super(StubUnpickler, self).find_class(mod, nm)
         return type(str(name), (_Stub,), {"__module__": module})
 
 

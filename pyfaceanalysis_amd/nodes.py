@@ -214,26 +214,51 @@ class iGSFANode(Node):
 
     Execute semantics restated from the published HiGSFA description (arXiv:1601.03945) and
     SURVEY.md §8a row a8 — source not available in this container, so this spec is owned by
-    the build:
+    the build and the two points where public descriptions of cuicuilco differ are EXPLICIT
+    fields of the node (and of its blob record), never an implicit choice:
 
         x0  = x - x_mean
         e   = exp_node(x0)                      (or x0 when exp_node is None)
-        s   = sfa_node(e) * magn_n_sfa_x        (per-column scale)
-        r   = x0 - lr_node(s)                   (when reconstruct_with_sfa, else r = x0)
+        n   = sfa_node(e)                       (normalised slow features)
+        s   = n * magn_n_sfa_x                  scaling == "per_column"  (sensitivity_based / data_dependent)
+            = n @ scaling_matrix                scaling == "matrix"      (QR_decomposition: scaling_matrix = R.T)
+        r   = x0 - lr_node(s)                   lr_input == "scaled"     (round-1 reading)
+            = x0 - lr_node(n)                   lr_input == "unscaled"   (reconstruction trained on the normalised features)
+            = x0                                when not reconstruct_with_sfa
         q   = pca_node(r)
         y   = hstack([s[:, :num_sfa_features_preserved], q])
     """
 
+    LR_INPUTS = ("scaled", "unscaled")
+    SCALINGS = ("per_column", "matrix")
+
     def __init__(self, x_mean, exp_node, sfa_node, magn_n_sfa_x, lr_node, pca_node,
-                 num_sfa_features_preserved, reconstruct_with_sfa=True):
+                 num_sfa_features_preserved, reconstruct_with_sfa=True, lr_input="scaled",
+                 scaling="per_column", scaling_matrix=None):
+        if lr_input not in self.LR_INPUTS:
+            raise ValueError("iGSFANode: lr_input must be one of %r" % (self.LR_INPUTS,))
+        if scaling not in self.SCALINGS:
+            raise ValueError("iGSFANode: scaling must be one of %r" % (self.SCALINGS,))
         self.sfa_node = sfa_node
         self.pca_node = pca_node
         self.exp_node = exp_node
         self.lr_node = lr_node if reconstruct_with_sfa else None
         self.reconstruct_with_sfa = bool(reconstruct_with_sfa)
+        self.lr_input = lr_input
+        self.scaling = scaling
         self.input_dim = int(pca_node.input_dim)
         self.x_mean = _f64(x_mean, (1, self.input_dim))
-        self.magn_n_sfa_x = _f64(magn_n_sfa_x, (1, sfa_node.output_dim))
+        k = sfa_node.output_dim
+        if scaling == "matrix":
+            if scaling_matrix is None:
+                raise ValueError("iGSFANode: scaling='matrix' needs scaling_matrix")
+            self.scaling_matrix = _f64(scaling_matrix, (k, k))
+            self.magn_n_sfa_x = np.ones((1, k))
+        else:
+            if scaling_matrix is not None:
+                raise ValueError("iGSFANode: scaling_matrix given with scaling='per_column'")
+            self.scaling_matrix = None
+            self.magn_n_sfa_x = _f64(magn_n_sfa_x, (1, k))
         self.num_sfa_features_preserved = int(num_sfa_features_preserved)
         if self.num_sfa_features_preserved > sfa_node.output_dim:
             raise ValueError("iGSFANode: num_sfa_features_preserved > sfa_node.output_dim")

@@ -6,8 +6,12 @@ The reference loads its networks with ``cache_obj.load_obj_from_cache`` = ``pick
 the module aliases of FaceDetectUpdated.py:57-68 on the path.  Here the pickle is read with
 ``classifier.StubUnpickler``: every non-numpy global becomes an attribute bag that remembers its
 module and class name, and this module maps those bags, by class NAME and MDP attribute names,
-onto ``pyfaceanalysis_amd.nodes``.  Unknown node classes or expansion functions raise — nothing
-is guessed.  The trained flows themselves are not shipped with the reference
+onto ``pyfaceanalysis_amd.nodes``.  Unknown node classes or expansion functions raise, and so does
+everything about a node that this converter does not understand and that could change its execute:
+an iGSFANode with a ``slow_feature_scaling_method`` outside the whitelist below, with numeric state the
+conversion does not consume, or whose linear-reconstruction input (scaled / unscaled slow features —
+public descriptions of cuicuilco differ, see ``nodes.iGSFANode``) the caller has not stated; a
+LinearRegressionNode without an intercept row.  The trained flows themselves are not shipped with the reference
 (.MISSING_LARGE_BLOBS), so this is exercised on synthetic pickles built under the same module /
 class names (tests/test_pickle_import.py).
 """
@@ -55,10 +59,41 @@ def convert_func(f):
     return _FUNCS[name]
 
 
-def convert_node(obj):
-    """One pickled node (stub) -> a pyfaceanalysis_amd.nodes object."""
+# iGSFANode.slow_feature_scaling_method -> how the scaled slow features are formed from the normalised ones.
+# [K] restated from public knowledge of cuicuilco's igsfa_node.py; anything else is refused.
+_IGSFA_SCALING = {
+    None: "none",                       # s = n
+    "sensitivity_based": "per_column",  # s = n * magn_n_sfa_x
+    "data_dependent": "per_column",
+    "QR_decomposition": "matrix",       # s = n @ R.T
+}
+# attributes an iGSFANode stub may carry that do not enter execute (training configuration / bookkeeping)
+_IGSFA_IGNORABLE = frozenset((
+    "_input_dim", "_output_dim", "_dtype", "input_dim", "output_dim", "dtype", "_train_phase", "_train_phase_started",
+    "_training", "_train_seq", "verbose", "pre_expansion_node_class", "pre_expansion_out_dim", "expansion_funcs",
+    "expansion_output_dim", "expansion_starting_point", "max_length_slow_part", "max_num_samples_for_ev",
+    "max_test_samples_for_ev", "offsetting_mode", "max_preserved_sfa", "out_sfa_filter", "delta_threshold",
+    "evar", "first_call", "sfa_x_mean", "sfa_x_std", "expanded_dim", "num_sfa_features_preserved_max"))
+
+
+def _is_numeric_state(v):
+    if isinstance(v, bool) or v is None:
+        return False
+    if isinstance(v, (int, float, complex, np.number)):
+        return True
+    return isinstance(v, np.ndarray) and v.dtype.kind in "fiuc"
+
+
+def convert_node(obj, igsfa_lr_input=None, ignore_attrs=()):
+    """One pickled node (stub) -> a pyfaceanalysis_amd.nodes object.
+
+    ``igsfa_lr_input``: "scaled" or "unscaled" — which slow features a pickled iGSFANode's ``lr_node`` reads
+    (``nodes.iGSFANode``).  Required as soon as an iGSFANode has both a reconstruction and a non-trivial
+    scaling; there is no default because the reference's source for it is not available.
+    ``ignore_attrs``: names of extra numeric attributes of iGSFANode stubs to accept unconsumed."""
     if obj is None:
         return None
+    kw = dict(igsfa_lr_input=igsfa_lr_input, ignore_attrs=ignore_attrs)
     name = _cls(obj)
     if name in ("PCANode", "WhiteningNode"):
         i, o = _dims(obj)
@@ -74,7 +109,13 @@ def convert_node(obj):
         cls = N.GSFANode if name == "GSFANode" else N.SFANode
         return cls(avg, sf, bias)
     if name == "LinearRegressionNode":
-        return N.LinearRegressionNode(np.asarray(_get(obj, "beta"), dtype=np.float64))
+        i, o = _dims(obj)
+        beta = np.asarray(_get(obj, "beta"), dtype=np.float64)
+        with_bias = _get(obj, "with_bias", default=True)
+        if not with_bias or beta.shape != (i + 1, o):
+            raise ValueError("LinearRegressionNode: only with_bias=True is covered (beta row 0 = intercept); the pickle has "
+                             "with_bias=%r and beta of shape %r for %d -> %d" % (with_bias, beta.shape, i, o))
+        return N.LinearRegressionNode(beta)
     if name == "GeneralExpansionNode":
         i, o = _dims(obj)
         node = N.GeneralExpansionNode([convert_func(f) for f in _get(obj, "funcs")], i)
@@ -82,15 +123,39 @@ def convert_node(obj):
             raise ValueError("GeneralExpansionNode: converted width %d != pickled output_dim %d" % (node.output_dim, o))
         return node
     if name in ("iGSFANode", "IEVMLRecNode"):
-        exp = convert_node(_get(obj, "exp_node", default=None))
-        sfa = convert_node(_get(obj, "sfa_node"))
-        pca = convert_node(_get(obj, "pca_node"))
+        consumed = {"x_mean", "exp_node", "sfa_node", "pca_node", "lr_node", "magn_n_sfa_x", "num_sfa_features_preserved",
+                    "reconstruct_with_sfa", "slow_feature_scaling_method", "R"}
+        exp = convert_node(_get(obj, "exp_node", default=None), **kw)
+        sfa = convert_node(_get(obj, "sfa_node"), **kw)
+        pca = convert_node(_get(obj, "pca_node"), **kw)
         rec = bool(_get(obj, "reconstruct_with_sfa", default=True))
-        lr = convert_node(_get(obj, "lr_node", default=None)) if rec else None
-        magn = np.asarray(_get(obj, "magn_n_sfa_x", default=np.ones(sfa.output_dim)), dtype=np.float64).reshape(-1)
+        lr = convert_node(_get(obj, "lr_node", default=None), **kw) if rec else None
         k = int(_get(obj, "num_sfa_features_preserved", default=sfa.output_dim))
+        method = obj.__dict__.get("slow_feature_scaling_method", "sensitivity_based" if "magn_n_sfa_x" in obj.__dict__ else None)
+        if method not in _IGSFA_SCALING:
+            raise ValueError("iGSFANode: slow_feature_scaling_method=%r is not covered (known: %s); refusing to convert rather "
+                             "than guess its execute" % (method, sorted(m for m in _IGSFA_SCALING if m)))
+        scaling, magn, matrix = _IGSFA_SCALING[method], None, None
+        if scaling == "matrix":
+            matrix = np.asarray(_get(obj, "R"), dtype=np.float64).T            # s = n @ R.T  [K]
+        elif scaling == "per_column":
+            magn = np.asarray(_get(obj, "magn_n_sfa_x"), dtype=np.float64).reshape(-1)
+        else:
+            scaling, magn = "per_column", np.ones(sfa.output_dim)
+        stray = sorted(a for a, v in obj.__dict__.items()
+                       if a not in consumed and a not in _IGSFA_IGNORABLE and a not in ignore_attrs and _is_numeric_state(v))
+        if stray:
+            raise ValueError("iGSFANode: pickled numeric state %s is not consumed by the conversion (assumed execute rule: "
+                             "s = sfa(exp(x - x_mean)) scaled by %s; r = x0 - lr(s or n); y = [s[:k], pca(r)]); pass "
+                             "ignore_attrs=%r if it does not enter execute" % (stray, method, tuple(stray)))
+        trivial = matrix is None and bool(np.all(magn == 1.0))
+        if lr is not None and rec and not trivial and igsfa_lr_input not in N.iGSFANode.LR_INPUTS:
+            raise ValueError("iGSFANode with a linear reconstruction and %s scaling: state igsfa_lr_input='scaled' (lr_node "
+                             "reads the scaled slow features) or 'unscaled' (the normalised ones) — the rule lives in cuicuilco "
+                             "@9bfd242, which is not available here, and the two give different features" % method)
         return N.iGSFANode(np.asarray(_get(obj, "x_mean"), dtype=np.float64).reshape(-1), exp, sfa, magn, lr, pca, k,
-                           reconstruct_with_sfa=rec and lr is not None)
+                           reconstruct_with_sfa=rec and lr is not None, lr_input=igsfa_lr_input or "scaled",
+                           scaling=scaling, scaling_matrix=matrix)
     if name in ("Switchboard", "PInvSwitchboard", "Rectangular2dSwitchboard", "Rectangular2dSwitchboardException",
                 "DoubleRect2dSwitchboard", "DoubleRhomb2dSwitchboard"):
         i, o = _dims(obj)
@@ -101,12 +166,12 @@ def convert_node(obj):
         return sb
     if name == "CloneLayer":
         nodes = _get(obj, "nodes")
-        return N.CloneLayer(convert_node(_get(obj, "node", default=nodes[0])), len(nodes))
+        return N.CloneLayer(convert_node(_get(obj, "node", default=nodes[0]), **kw), len(nodes))
     if name == "Layer":
-        return N.Layer([convert_node(n) for n in _get(obj, "nodes")])
+        return N.Layer([convert_node(n, **kw) for n in _get(obj, "nodes")])
     if name == "FlowNode":
         inner = _get(obj, "_flow", "flow")
-        return N.FlowNode(convert_flow_object(inner))
+        return N.FlowNode(convert_flow_object(inner, **kw))
     if name == "IdentityNode":
         return N.IdentityNode(_dims(obj)[0])
     if name == "HeadNode":
@@ -117,27 +182,31 @@ def convert_node(obj):
                     % (getattr(type(obj), "__module__", "?"), name))
 
 
-def convert_flow_object(flow_obj):
+def convert_flow_object(flow_obj, **kw):
     """A pickled mdp.Flow (attribute ``flow``: list of nodes) or a plain list -> list of description nodes."""
     seq = flow_obj if isinstance(flow_obj, (list, tuple)) else _get(flow_obj, "flow")
-    out = [convert_node(n) for n in seq]
+    out = [convert_node(n, **kw) for n in seq]
     for a, b in zip(out[:-1], out[1:]):
         if a.output_dim != b.input_dim:
             raise ValueError("converted flow: %r -> %r dimension mismatch" % (a, b))
     return out
 
 
-def load_flow_pickle(path):
-    return convert_flow_object(load_stub_pickle(path))
+def load_flow_pickle(path, igsfa_lr_input=None, ignore_attrs=()):
+    return convert_flow_object(load_stub_pickle(path), igsfa_lr_input=igsfa_lr_input, ignore_attrs=ignore_attrs)
 
 
-def pickle_to_blob(path):
-    return flow_to_blob(load_flow_pickle(path))
+def pickle_to_blob(path, igsfa_lr_input=None, ignore_attrs=()):
+    return flow_to_blob(load_flow_pickle(path, igsfa_lr_input=igsfa_lr_input, ignore_attrs=ignore_attrs))
 
 
 if __name__ == "__main__":
-    import sys
-    if len(sys.argv) != 3:
-        sys.exit("usage: python -m pyfaceanalysis_amd.pickle_import SavedNetworks/<flow>.pckl out.hgflow")
-    with open(sys.argv[2], "wb") as fh:
-        fh.write(pickle_to_blob(sys.argv[1]))
+    import argparse
+    ap = argparse.ArgumentParser(description="SavedNetworks/<flow>.pckl -> neutral flow blob, without mdp / cuicuilco")
+    ap.add_argument("pickle")
+    ap.add_argument("out")
+    ap.add_argument("--igsfa-lr-input", choices=N.iGSFANode.LR_INPUTS, default=None,
+                    help="which slow features the iGSFA linear reconstruction reads (no default: see nodes.iGSFANode)")
+    a = ap.parse_args()
+    with open(a.out, "wb") as fh:
+        fh.write(pickle_to_blob(a.pickle, igsfa_lr_input=a.igsfa_lr_input))

@@ -125,10 +125,15 @@ def fuzz_net(seed):
     return flow
 
 
-def fuzz_igsfa_net(seed):
+def fuzz_igsfa_net(seed, lr_input=None, scaling=None):
     """Random hierarchy of iGSFA nodes: random widths, with / without the linear
-    reconstruction and the expansion, merges in x / y / 2x2, uneven slow-feature counts across layers."""
+    reconstruction and the expansion, merges in x / y / 2x2, uneven slow-feature counts across layers.
+    The node variants (which slow features the reconstruction reads; per-column or matrix scaling) cycle with
+    the seed unless given."""
     rng = np.random.default_rng(5000 + seed)
+    rng_v = np.random.default_rng(9000 + seed)       # separate stream: the nets of round 1 keep their weights
+    lr_input = lr_input or ("unscaled" if seed % 3 == 1 else "scaled")
+    scaling = scaling or ("matrix" if seed % 4 == 2 else "per_column")
     w, h = (int(v) for v in rng.choice([4, 6, 8], 2))
     fx, fy = (int(v) for v in rng.choice([2, 3, 4], 2))
     fx, fy = min(fx, w), min(fy, h)
@@ -162,8 +167,12 @@ def fuzz_igsfa_net(seed):
             lr = N.LinearRegressionNode(rng.normal(size=(k + 1, d_in)) / np.sqrt(k + 1))
             pca = rand_pca(rng, d_in, q)
             pca.avg = np.zeros_like(pca.avg)                   # the residual is centred by construction
-            return N.iGSFANode(rng.normal(size=d_in), ex, sfa, rng.uniform(0.5, 2.0, size=k), lr, pca, k,
-                               reconstruct_with_sfa=with_lr)
+            magn = rng.uniform(0.5, 2.0, size=k)
+            mat = None
+            if scaling == "matrix":        # like the R of a QR decomposition: triangular, well conditioned
+                mat = np.triu(rng_v.normal(size=(k, k)) * 0.3, 1) + np.diag(rng_v.uniform(0.5, 2.0, size=k))
+            return N.iGSFANode(rng.normal(size=d_in), ex, sfa, None if mat is not None else magn, lr, pca, k,
+                               reconstruct_with_sfa=with_lr, lr_input=lr_input, scaling=scaling, scaling_matrix=mat)
 
         layer = N.Layer([make() for _ in range(n_nodes)])
         flow += [sb, layer]

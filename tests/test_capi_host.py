@@ -111,6 +111,57 @@ def test_malformed_blobs_are_rejected(native_lib):
     assert rc == _capi.HG_ERR_ARG
 
 
+def test_malformed_expansion_records_are_rejected(native_lib):
+    """Expansion selections / offsets the device would turn into out-of-range reads are refused at load time."""
+    def net(func, p=8):
+        rng = np.random.default_rng(0)
+        ex = N.GeneralExpansionNode([N.identity, func], p)
+        return [N.Layer([N.FlowNode([helpers.rand_pca(rng, 6, p), ex, helpers.rand_sfa(rng, ex.output_dim, 4)])])]
+
+    def patched(func, **fields):
+        good = blob.flow_to_blob(net(func))
+        rec = struct.pack("<IIIId", blob._EXP_KIND[func.kind], func.sel, func.k, 0, func.expo)
+        off = good.index(rec)
+        kind, sel, k, expo = blob._EXP_KIND[func.kind], func.sel, func.k, func.expo
+        kind, sel, k, expo = fields.get("kind", kind), fields.get("sel", sel), fields.get("k", k), fields.get("expo", expo)
+        return good[:off] + struct.pack("<IIIId", kind, sel, k, 0, expo) + good[off + 24:]
+
+    cases = [patched(N.pair_prodsadj1_ex, k=0xFFFFFFFF),        # x_i * x_{i-1}: reads below the block
+             patched(N.pair_prodsadj1_ex, k=0), patched(N.pair_prodsadj1_ex, k=8),
+             patched(N.QT, sel=0xFFFFFFFE), patched(N.QT, sel=9),
+             patched(N.unsigned_08expo, expo=float("nan")), patched(N.unsigned_08expo, expo=-0.5),
+             patched(N.signed_08expo, expo=float("inf"))]
+    for b in cases:
+        rc, h = _load(native_lib, b)
+        assert rc in (_capi.HG_ERR_FORMAT, _capi.HG_ERR_DIM), native_lib.hg_last_error()
+        assert b"expansion" in native_lib.hg_last_error()
+    for ok in (net(N.pair_prodsadj1_ex), net(N.QT), net(N.sel_exp(3, N.QT)), net(N.unsigned_expo(1.3))):
+        rc, h = _load(native_lib, blob.flow_to_blob(ok))
+        assert rc == 0, native_lib.hg_last_error()
+        native_lib.hg_flow_free(h)
+
+
+def test_igsfa_record_variants_load(native_lib):
+    """The IGSFA record's flags (lr on scaled / unscaled features, per-column / matrix scaling) parse and plan on the
+    host; unknown flag bits and a singular scaling with lr_input='unscaled' are refused."""
+    for seed in range(6):
+        nodes = helpers.fuzz_igsfa_net(seed)
+        inf, _ = Flow(nodes).host_plan()
+        assert inf.input_dim == nodes[0].input_dim and inf.output_dim == nodes[-1].output_dim
+    nodes = helpers.fuzz_igsfa_net(1, lr_input="unscaled", scaling="per_column")
+    for ig in nodes[1].nodes:
+        ig.magn_n_sfa_x[0, 0] = 0.0
+    if nodes[1].nodes[0].lr_node is not None:
+        rc, h = _load(native_lib, blob.flow_to_blob(nodes))
+        assert rc == _capi.HG_ERR_FORMAT and b"singular" in native_lib.hg_last_error()
+    good = blob.flow_to_blob(helpers.fuzz_igsfa_net(0))
+    off = good.index(struct.pack("<II", 1, 1)) if struct.pack("<II", 1, 1) in good else -1
+    assert off > 0
+    bad = good[:off] + struct.pack("<II", 1, 9) + good[off + 8:]
+    rc, h = _load(native_lib, bad)
+    assert rc == _capi.HG_ERR_FORMAT
+
+
 def test_python_blob_validation():
     with pytest.raises(ValueError):
         blob.flow_to_blob([])

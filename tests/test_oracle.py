@@ -158,3 +158,29 @@ def test_fuzzed_hierarchies_host_side(seed):
     a = oracle.execute_flow(nodes, x)
     assert np.abs(a - ref_c.execute_flow(nodes, x)).max() <= 1e-12 * np.abs(a).max()
     assert np.array_equal(a, oracle.execute_flow(blob_to_flow(flow_to_blob(nodes)), x))
+
+
+@pytest.mark.parametrize("seed", [1, 2, 10, 22])
+def test_igsfa_variants_host_side(seed):
+    """iGSFA record variants (lr on scaled / unscaled features, per-column / matrix scaling): both restatements agree,
+    the blob round-trips, and the rewrite the native loader applies (hg_tree.cpp normalise_igsfa: every variant
+    expressed as 'per-column scale 1, lr on the scaled features') is the same map."""
+    from pyfaceanalysis_amd.blob import flow_to_blob
+    nodes = helpers.fuzz_igsfa_net(seed)
+    x = np.random.default_rng(seed).normal(size=(11, nodes[0].input_dim)) * 1.5
+    a = oracle.execute_flow(nodes, x)
+    assert np.abs(a - ref_c.execute_flow(nodes, x)).max() <= 1e-12 * np.abs(a).max()
+    assert np.array_equal(a, oracle.execute_flow(blob_to_flow(flow_to_blob(nodes)), x))
+
+    def rewritten(ig):
+        k = ig.sfa_node.output_dim
+        M = ig.scaling_matrix if ig.scaling == "matrix" else np.diag(ig.magn_n_sfa_x.reshape(-1))
+        sfa = N.SFANode(np.zeros(ig.sfa_node.input_dim), ig.sfa_node.sf @ M, ig.sfa_node._bias @ M)
+        lr = ig.lr_node
+        if lr is not None and ig.lr_input == "unscaled":       # lr(n) = lr(s M^-1)
+            lr = N.LinearRegressionNode(np.vstack([lr.beta[0:1], np.linalg.solve(M, lr.beta[1:])]))
+        return N.iGSFANode(ig.x_mean, ig.exp_node, sfa, np.ones(k), lr, ig.pca_node, ig.num_sfa_features_preserved,
+                           reconstruct_with_sfa=ig.reconstruct_with_sfa)
+    legacy = [N.Layer([rewritten(n) for n in nd.nodes]) if isinstance(nd, N.Layer) else nd for nd in nodes]
+    b = oracle.execute_flow(legacy, x)
+    assert np.abs(a - b).max() <= 1e-10 * np.abs(a).max()

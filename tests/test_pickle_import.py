@@ -72,10 +72,12 @@ def _to_fake(node, mods, C):
     if name == "FlowNode":
         return bag(C[name], _flow=bag(C["Flow"], flow=[_to_fake(n, mods, C) for n in node.flow]), **io)
     if name == "iGSFANode":
+        extra = dict(slow_feature_scaling_method="QR_decomposition", R=node.scaling_matrix.T) if node.scaling == "matrix" \
+            else dict(slow_feature_scaling_method="sensitivity_based", magn_n_sfa_x=node.magn_n_sfa_x)
         return bag(C[name], x_mean=node.x_mean, exp_node=_to_fake(node.exp_node, mods, C), sfa_node=_to_fake(node.sfa_node, mods, C),
-                   pca_node=_to_fake(node.pca_node, mods, C), lr_node=_to_fake(node.lr_node, mods, C),
-                   magn_n_sfa_x=node.magn_n_sfa_x, num_sfa_features_preserved=node.num_sfa_features_preserved,
-                   reconstruct_with_sfa=True, **io)
+                   pca_node=_to_fake(node.pca_node, mods, C), lr_node=_to_fake(node.lr_node, mods, C) if node.lr_node is not None else None,
+                   num_sfa_features_preserved=node.num_sfa_features_preserved, reconstruct_with_sfa=node.reconstruct_with_sfa,
+                   verbose=False, delta_threshold=1.99, **dict(extra, **io))
     raise TypeError(name)
 
 
@@ -107,10 +109,89 @@ def test_roundtrip_through_fake_mdp_pickle(tmp_path, nets, case):
     mods, C = _fake_modules()
     path = _dump(tmp_path, nodes, mods, C, as_tuple=(case == "trained"))
     assert "mdp" not in sys.modules and "more_nodes" not in sys.modules          # really no mdp around
-    got = pickle_import.load_flow_pickle(path)
+    if case == "igsfa":       # the reconstruction input must be stated, never assumed
+        with pytest.raises(ValueError, match="igsfa_lr_input"):
+            pickle_import.load_flow_pickle(path)
+    got = pickle_import.load_flow_pickle(path, igsfa_lr_input="scaled" if case == "igsfa" else None)
     x = np.random.default_rng(0).normal(size=(9, nodes[0].input_dim)) * 3 + 100
     assert np.array_equal(oracle.execute_flow(got, x), oracle.execute_flow(nodes, x))
-    assert flow_to_blob(got) == flow_to_blob(blob_to_flow(pickle_import.pickle_to_blob(path)))
+    assert flow_to_blob(got) == flow_to_blob(blob_to_flow(pickle_import.pickle_to_blob(path, igsfa_lr_input="scaled")))
+
+
+@pytest.mark.parametrize("seed", [4, 2, 22, 13])        # unscaled + per-column, scaled + matrix (QR), unscaled + matrix
+def test_igsfa_variants_roundtrip(tmp_path, seed):
+    nodes = helpers.fuzz_igsfa_net(seed)
+    ig = nodes[1].nodes[0]
+    mods, C = _fake_modules()
+    path = _dump(tmp_path, nodes, mods, C)
+    got = pickle_import.load_flow_pickle(path, igsfa_lr_input=ig.lr_input)
+    assert got[1].nodes[0].scaling == ig.scaling and got[1].nodes[0].lr_input == ig.lr_input
+    x = np.random.default_rng(0).normal(size=(7, nodes[0].input_dim))
+    assert np.array_equal(oracle.execute_flow(got, x), oracle.execute_flow(nodes, x))
+    # through the blob (flags of the IGSFA record) and back
+    back = blob_to_flow(flow_to_blob(got))
+    assert np.array_equal(oracle.execute_flow(back, x), oracle.execute_flow(nodes, x))
+    if ig.lr_node is not None:       # the other reading gives different features: the field matters
+        other = pickle_import.load_flow_pickle(path, igsfa_lr_input="scaled" if ig.lr_input == "unscaled" else "unscaled")
+        assert not np.allclose(oracle.execute_flow(other, x), oracle.execute_flow(nodes, x))
+
+
+def test_igsfa_unknown_state_is_refused(tmp_path):
+    nodes = helpers.fuzz_igsfa_net(0)
+    mods, C = _fake_modules()
+
+    def dump_with(**attrs):
+        flow = C["Flow"]()
+        flow.flow = [_to_fake(n, mods, C) for n in nodes]
+        flow.flow[1].nodes[0].__dict__.update(attrs)
+        sys.modules.update(mods)
+        try:
+            data = pickle.dumps(flow, protocol=2)
+        finally:
+            for k in mods:
+                sys.modules.pop(k, None)
+        p = tmp_path / "f.pckl"
+        p.write_bytes(data)
+        return str(p)
+
+    with pytest.raises(ValueError, match="slow_feature_scaling_method='fancy_new_method'"):
+        pickle_import.load_flow_pickle(dump_with(slow_feature_scaling_method="fancy_new_method"), igsfa_lr_input="scaled")
+    with pytest.raises(ValueError, match="sfa_feature_std"):
+        pickle_import.load_flow_pickle(dump_with(sfa_feature_std=np.ones(3)), igsfa_lr_input="scaled")
+    pickle_import.load_flow_pickle(dump_with(sfa_feature_std=np.ones(3)), igsfa_lr_input="scaled", ignore_attrs=("sfa_feature_std",))
+    # LinearRegressionNode without an intercept row
+    lr = nodes[1].nodes[0].lr_node
+    if lr is not None:
+        flow = C["Flow"]()
+        flow.flow = [_to_fake(lr, mods, C)]
+        flow.flow[0].__dict__.update(with_bias=False)
+        sys.modules.update(mods)
+        try:
+            data = pickle.dumps(flow, protocol=2)
+        finally:
+            for k in mods:
+                sys.modules.pop(k, None)
+        (tmp_path / "lr.pckl").write_bytes(data)
+        with pytest.raises(ValueError, match="with_bias"):
+            pickle_import.load_flow_pickle(str(tmp_path / "lr.pckl"))
+
+
+def test_stub_unpickler_resolves_only_the_allowlist(tmp_path):
+    """A pickle that names eval / os.system / numpy.testing helpers gets inert stubs, not the real objects."""
+    from pyfaceanalysis_amd.classifier import load_stub_pickle, _Stub
+    evil = b"c__builtin__\neval\n(S'1+1'\ntR."                   # protocol-0: eval('1+1')
+    (tmp_path / "e.pckl").write_bytes(evil)
+    out = load_stub_pickle(str(tmp_path / "e.pckl"))
+    assert isinstance(out, _Stub) and type(out).__name__ == "eval"
+    for mod, name in (("os", "system"), ("numpy.testing", "run_module_suite"), ("builtins", "getattr"), ("numpy", "load")):
+        data = b"c" + mod.encode() + b"\n" + name.encode() + b"\n."
+        (tmp_path / "g.pckl").write_bytes(data)
+        cls = load_stub_pickle(str(tmp_path / "g.pckl"))
+        assert isinstance(cls, type) and issubclass(cls, _Stub)
+    arr = {"a": np.arange(6.0).reshape(2, 3), "b": [np.float64(2.5), 3, "s"]}
+    (tmp_path / "n.pckl").write_bytes(pickle.dumps(arr, protocol=2))
+    back = load_stub_pickle(str(tmp_path / "n.pckl"))
+    assert np.array_equal(back["a"], arr["a"]) and back["b"] == arr["b"]
 
 
 def test_unknown_classes_fail_loudly(tmp_path):
