@@ -97,9 +97,23 @@ int hg_flow_reserve(hg_flow* f, int64_t max_rows);
  * y: n rows, the first y_cols (<= output_dim) columns, row stride ldy elements.  The caller
  * usually wants only the first classifier.input_dim columns (FaceDetectUpdated.py:709,719).
  * n == 0 is valid and a no-op (reference guards len(subimages_arr) > 0 at :694).
- * Synchronous: returns after y is complete. */
+ * Synchronous: returns after y is complete.  Rows go through pinned double-buffered staging (the copy of chunk
+ * i+1 overlaps the kernels of chunk i); float32 / float64 chunks whose values are all integers 0..255 — what
+ * images_asarray produces (face_analysis.py:786) — cross PCIe as uint8, which changes no output bit. */
 int hg_flow_execute(hg_flow* f, const void* x, int x_dtype, int64_t n, int64_t ldx,
                     void* y, int y_dtype, int64_t y_cols, int64_t ldy);
+
+/* The same call over several devices of this process (sub-images are independent, so the batch is
+ * cut into n_devices contiguous row blocks of ceil(n / n_devices) rows; block r runs on devices[r] with replicated
+ * weights, its own streams and staging buffers, driven by its own host thread; every block's features land in the
+ * caller's y at the block's rows — with host buffers that IS the gather, no peer copy or collective is needed).
+ * devices == NULL means 0 .. n_devices-1; a device may be listed more than once (each entry is a replica).
+ * Replicas are created on first use and kept in the handle; hg_flow_to_device is not required.
+ * Multi-process callers (one rank per GPU, RCCL all-gather of device-resident features) use
+ * hg_flow_execute_device per rank instead: pyfaceanalysis_amd/sharded.py. */
+int hg_flow_execute_sharded(hg_flow* f, const void* x, int x_dtype, int64_t n, int64_t ldx,
+                            void* y, int y_dtype, int64_t y_cols, int64_t ldy,
+                            const int* devices, int n_devices);
 
 /* Same with DEVICE buffers on the flow's device, enqueued on `stream` (hipStream_t, may be
  * null = default stream); returns without synchronising. */

@@ -12,15 +12,41 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhigsfa.so")
-SOURCES = ["hg_tree.cpp", "hg_capi.cpp", "hg_generic.hip", "hg_fused.hip", "hg_fused_front.hip", "hg_fused_igsfa.hip",
+SOURCES = ["hg_tree.cpp", "hg_capi.cpp", "hg_hostpack.cpp", "hg_generic.hip", "hg_fused.hip", "hg_fused_front.hip", "hg_fused_igsfa.hip",
            "hg_gauss.hip", "hg_extract.hip", "hg_train.hip"]
 HEADERS = ["hg_common.hpp", os.path.join("..", "..", "include", "higsfa.h")]
+HOST_ONLY = {"hg_hostpack.cpp"}      # no HIP in them: built with g++ (function multiversioning, which the device pass rejects)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+CXX = os.environ.get("CXX", "g++")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-unused-result"]
 
 
 def _newer(a, b):
     return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
+
+
+def _header_paths():
+    hdr = [os.path.join(CSRC, h) for h in HEADERS]
+    return hdr + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith((".hpp", ".h", ".inc"))]
+
+
+def is_stale():
+    """True when build() would compile or link something (pure mtime checks, starts no process)."""
+    if not os.path.exists(LIB):
+        return True
+    hdr = _header_paths()
+    for src in SOURCES:
+        sp, op = os.path.join(CSRC, src), os.path.join(CSRC, "_obj", src + ".o")
+        if _newer(sp, op) or any(_newer(h, op) for h in hdr) or _newer(op, LIB):
+            return True
+    return False
+
+
+def oracle_is_stale(oracle_dir):
+    """Same for the oracle's C restatements (oracle/Makefile): a .c newer than the .so built from it."""
+    pairs = (("ref_c.c", "libref_c.so"), ("fast_cpu.c", "libfast_cpu.so"), ("fast_cpu_pow.c", "libfast_cpu.so"))
+    return any(os.path.exists(os.path.join(oracle_dir, c)) and _newer(os.path.join(oracle_dir, c), os.path.join(oracle_dir, so))
+               for c, so in pairs)
 
 
 def build(force=False, verbose=False):
@@ -36,7 +62,10 @@ def build(force=False, verbose=False):
         op = os.path.join(objdir, src + ".o")
         objs.append(op)
         if force or _newer(sp, op) or any(_newer(h, op) for h in hdr_paths):
-            cmd = [HIPCC] + FLAGS + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", sp, "-o", op]
+            if src in HOST_ONLY:
+                cmd = [CXX, "-O3", "-std=c++17", "-fPIC", "-Wall", "-c", sp, "-o", op]
+            else:
+                cmd = [HIPCC] + FLAGS + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", sp, "-o", op]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

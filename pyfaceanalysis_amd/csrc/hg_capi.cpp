@@ -1,6 +1,10 @@
 // C ABI (include/higsfa.h): flow handle, host/device execute, profiling.
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
+#include <thread>
 
 #include "hg_common.hpp"
 
@@ -31,17 +35,168 @@ namespace hg {
 void set_last_error(const std::string& s) { g_last_error = s; }
 }  // namespace hg
 
+namespace {
+
+// ---- host worker pool: packs caller rows into pinned staging buffers while the GPU works ------------
+// One parallel region at a time (callers from several threads queue up); workers are created on first use.
+class HostPool {
+public:
+    static HostPool& get() {
+        static HostPool p;
+        return p;
+    }
+    int size() const { return (int)workers_.size() + 1; }
+    // fn(task) for task in [0, n_tasks); the calling thread takes part.
+    void parallel_for(int n_tasks, const std::function<void(int)>& fn) {
+        if (n_tasks <= 1 || workers_.empty()) {
+            for (int t = 0; t < n_tasks; ++t) fn(t);
+            return;
+        }
+        std::lock_guard<std::mutex> region(region_);
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            fn_ = &fn;
+            n_tasks_ = n_tasks;
+            next_.store(0);
+            pending_ = n_tasks;
+            ++gen_;
+        }
+        cv_.notify_all();
+        work();
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [&] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+
+private:
+    HostPool() {
+        int n = (int)std::thread::hardware_concurrency();
+        if (const char* e = getenv("HIGSFA_HOST_THREADS")) n = atoi(e);
+        n = std::max(1, std::min(n, 16));
+        for (int i = 1; i < n; ++i) workers_.emplace_back([this] { loop(); });
+    }
+    ~HostPool() {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto& w : workers_) w.join();
+    }
+    void work() {
+        for (;;) {
+            const int t = next_.fetch_add(1);
+            if (t >= n_tasks_) return;
+            (*fn_)(t);
+            std::lock_guard<std::mutex> lk(m_);
+            if (--pending_ == 0) done_.notify_all();
+        }
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+                if (stop_) return;
+                seen = gen_;
+            }
+            work();
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex m_, region_;
+    std::condition_variable cv_, done_;
+    const std::function<void(int)>* fn_ = nullptr;
+    std::atomic<int> next_{0};
+    int n_tasks_ = 0, pending_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+};
+
+}  // namespace
+
+namespace hg {
+// hg_hostpack.cpp (plain C++, built with g++ so that it can carry AVX2 clones): row of wide values -> uint8 when every
+// value is an integer 0..255; false otherwise.
+bool narrow_row_f64(const double* src, uint8_t* dst, int64_t n);
+bool narrow_row_f32(const float* src, uint8_t* dst, int64_t n);
+}  // namespace hg
+
+namespace {
+
+// One execution context: the executor on one device with its streams and staging buffers.
+struct Replica {
+    int device = -1;
+    std::unique_ptr<hg::Executor> exec;
+    hipStream_t compute = nullptr, copy = nullptr;
+    void* hx[2] = {nullptr, nullptr};      // pinned host staging, two slots
+    void* hy[2] = {nullptr, nullptr};
+    size_t hx_bytes = 0, hy_bytes = 0;
+    hg::DevBuf dx[2], dy[2];
+    hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+
+    void create(int dev) {
+        HG_HIP(hipSetDevice(dev));
+        exec->to_device();
+        HG_HIP(hipStreamCreateWithFlags(&compute, hipStreamNonBlocking));
+        HG_HIP(hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
+        for (int b = 0; b < 2; ++b) {
+            HG_HIP(hipEventCreateWithFlags(&ev_h2d[b], hipEventDisableTiming));
+            HG_HIP(hipEventCreateWithFlags(&ev_out[b], hipEventDisableTiming));
+        }
+        HG_HIP(hipDeviceSynchronize());
+        device = dev;
+    }
+    void need_pinned(size_t xb, size_t yb) {
+        if (xb > hx_bytes) {
+            for (int b = 0; b < 2; ++b) {
+                if (hx[b]) (void)hipHostFree(hx[b]);
+                hx[b] = nullptr;
+                HG_HIP(hipHostMalloc(&hx[b], xb, hipHostMallocDefault));
+            }
+            hx_bytes = xb;
+        }
+        if (yb > hy_bytes) {
+            for (int b = 0; b < 2; ++b) {
+                if (hy[b]) (void)hipHostFree(hy[b]);
+                hy[b] = nullptr;
+                HG_HIP(hipHostMalloc(&hy[b], yb, hipHostMallocDefault));
+            }
+            hy_bytes = yb;
+        }
+    }
+    void destroy() {
+        if (device < 0 || hipSetDevice(device) != hipSuccess) return;
+        for (int b = 0; b < 2; ++b) {
+            if (hx[b]) (void)hipHostFree(hx[b]);
+            if (hy[b]) (void)hipHostFree(hy[b]);
+            if (ev_h2d[b]) (void)hipEventDestroy(ev_h2d[b]);
+            if (ev_out[b]) (void)hipEventDestroy(ev_out[b]);
+            dx[b].free();
+            dy[b].free();
+            hx[b] = hy[b] = nullptr;
+        }
+        if (compute) (void)hipStreamDestroy(compute);
+        if (copy) (void)hipStreamDestroy(copy);
+        if (exec) exec->release();
+        device = -1;
+    }
+};
+
+}  // namespace
+
 struct hg_flow {
     std::unique_ptr<hg::TNode> root;
-    std::unique_ptr<hg::Executor> exec;
+    Replica main;                                   // the handle's own device (hg_flow_to_device)
+    std::vector<std::unique_ptr<Replica>> shards;   // replicas of hg_flow_execute_sharded, one per listed device
+    std::unique_ptr<hg::Executor>& exec = main.exec;
     std::string fused_reject;  // why the fused plan was not chosen ("" if it was)
-    int device = -1;
+    int& device = main.device;
     int64_t flops = 0;
-    bool profiling = false;
+    bool profiling = false, force_generic = false;
     std::vector<hipEvent_t> events;
     std::vector<hg::StageProfile> prof;
-    hipStream_t own_stream = nullptr;
-    hg::DevBuf stage_x, stage_y;
 
     void need_device() const {
         if (device < 0) hg::fail(HG_ERR_DEVICE, "flow is not on a device: call hg_flow_to_device first");
@@ -52,13 +207,9 @@ struct hg_flow {
         events.clear();
     }
     ~hg_flow() {
-        if (device >= 0 && hipSetDevice(device) == hipSuccess) {
-            drop_events();
-            if (own_stream) (void)hipStreamDestroy(own_stream);
-            if (exec) exec->release();
-            stage_x.free();
-            stage_y.free();
-        }
+        if (device >= 0 && hipSetDevice(device) == hipSuccess) drop_events();
+        main.destroy();
+        for (auto& r : shards) r->destroy();
     }
 };
 
@@ -79,8 +230,12 @@ void check_exec_args(const hg_flow* f, const void* x, int x_dtype, int64_t n, in
 }
 
 void run_on_device(hg_flow* f, const void* x, int x_dtype, int64_t n, int64_t ldx, void* y, int y_dtype, int64_t y_cols,
-                   int64_t ldy, hipStream_t st) {
+                   int64_t ldy, hipStream_t st, Replica* rep = nullptr) {
     if (n == 0) return;
+    if (rep && rep != &f->main) {      // shard replicas: never profiled (the benchmark= kwarg belongs to the handle's own device)
+        rep->exec->run(x, x_dtype, n, ldx, y, y_dtype, y_cols, ldy, st, nullptr);
+        return;
+    }
     hipEvent_t* ev = nullptr;
     const int ns = f->exec->n_stages();
     if (f->profiling) {
@@ -108,6 +263,92 @@ void run_on_device(hg_flow* f, const void* x, int x_dtype, int64_t n, int64_t ld
     }
 }
 
+
+// Host rows -> device -> host rows through one replica: chunks of rows are packed into pinned staging slot b
+// (narrowed to uint8 when every value is an integer 0..255), copied on the copy stream while the previous chunk's
+// kernels run on the compute stream, and the features come back through a pinned slot as well.
+//   slot reuse: hx[b] after ev_h2d[b] (its H2D done); dx[b] / dy[b] / hy[b] after ev_out[b] (kernels + D2H of the
+//   chunk that used the slot done).
+void run_host_rows(hg_flow* f, Replica& rep, const void* x, int x_dtype, int64_t n, int64_t ldx, void* y, int y_dtype, int64_t y_cols,
+                   int64_t ldy, bool use_pool) {
+    const size_t xs = hg::dtype_size(x_dtype), ys = hg::dtype_size(y_dtype);
+    const int64_t in_dim = f->root->in_dim;
+    // ~32 MiB of caller bytes per chunk (>= 256 rows): small enough to pipeline a 4096-row float64 batch in 16 chunks,
+    // large enough that a chunk's kernels are past their launch-latency floor
+    int64_t chunk = std::max<int64_t>(256, (32ll << 20) / (in_dim * (int64_t)xs));
+    chunk = std::min(chunk, n);
+    chunk = (chunk + 15) / 16 * 16;
+    const size_t x_slot = (size_t)chunk * in_dim * xs, y_slot = (size_t)chunk * y_cols * ys;
+    rep.need_pinned(x_slot, y_slot);
+    for (int b = 0; b < 2; ++b) {
+        rep.dx[b].alloc(x_slot);
+        rep.dy[b].alloc(y_slot);
+    }
+    rep.exec->reserve(chunk);
+    const bool try_narrow = x_dtype != HG_U8 && !getenv("HIGSFA_NO_NARROW");
+    HostPool& pool = HostPool::get();
+    const int64_t n_chunks = (n + chunk - 1) / chunk;
+    auto unpack = [&](int64_t ci) {      // features of chunk ci: pinned slot -> caller rows
+        const int b = (int)(ci & 1);
+        const int64_t r0 = ci * chunk, m = std::min(chunk, n - r0);
+        HG_HIP(hipEventSynchronize(rep.ev_out[b]));
+        const char* src = (const char*)rep.hy[b];
+        char* dst = (char*)y + (size_t)r0 * ldy * ys;
+        const size_t row = (size_t)y_cols * ys;
+        if (ldy == y_cols) memcpy(dst, src, row * m);
+        else for (int64_t r = 0; r < m; ++r) memcpy(dst + (size_t)r * ldy * ys, src + (size_t)r * row, row);
+    };
+    for (int64_t ci = 0; ci < n_chunks; ++ci) {
+        const int b = (int)(ci & 1);
+        const int64_t r0 = ci * chunk, m = std::min(chunk, n - r0);
+        if (ci >= 2) {
+            unpack(ci - 2);                               // frees hy[b] (and tells us dx[b] / dy[b] are free)
+            HG_HIP(hipEventSynchronize(rep.ev_h2d[b]));   // hx[b] has left the host
+        }
+        // ---- pack (host threads), overlapping the GPU work of chunk ci - 1
+        const char* xsrc = (const char*)x + (size_t)r0 * ldx * xs;
+        int sent_dtype = x_dtype;
+        if (try_narrow) {
+            std::atomic<int> ok{1};
+            const int tasks = (int)std::min<int64_t>(m, use_pool ? 4 * pool.size() : 1);
+            auto body = [&](int t) {
+                const int64_t a = m * t / tasks, e = m * (t + 1) / tasks;
+                for (int64_t r = a; r < e && ok.load(std::memory_order_relaxed); ++r) {
+                    const bool good = x_dtype == HG_F64
+                                          ? hg::narrow_row_f64((const double*)(xsrc + (size_t)r * ldx * xs), (uint8_t*)rep.hx[b] + (size_t)r * in_dim, in_dim)
+                                          : hg::narrow_row_f32((const float*)(xsrc + (size_t)r * ldx * xs), (uint8_t*)rep.hx[b] + (size_t)r * in_dim, in_dim);
+                    if (!good) ok.store(0, std::memory_order_relaxed);
+                }
+            };
+            if (use_pool) pool.parallel_for(tasks, body);
+            else body(0);
+            if (ok.load()) sent_dtype = HG_U8;
+        }
+        const size_t ss = hg::dtype_size(sent_dtype);
+        if (sent_dtype == x_dtype) {      // as given: rows copied into the pinned slot (strided source allowed)
+            const int tasks = (int)std::min<int64_t>(m, use_pool ? 4 * pool.size() : 1);
+            auto body = [&](int t) {
+                const int64_t a = m * t / tasks, e = m * (t + 1) / tasks;
+                if (ldx == in_dim) memcpy((char*)rep.hx[b] + (size_t)a * in_dim * xs, xsrc + (size_t)a * in_dim * xs, (size_t)(e - a) * in_dim * xs);
+                else for (int64_t r = a; r < e; ++r) memcpy((char*)rep.hx[b] + (size_t)r * in_dim * xs, xsrc + (size_t)r * ldx * xs, (size_t)in_dim * xs);
+            };
+            if (use_pool) pool.parallel_for(tasks, body);
+            else body(0);
+        }
+        // ---- copy stream: H2D once the slot's previous consumer is done
+        if (ci >= 2) HG_HIP(hipStreamWaitEvent(rep.copy, rep.ev_out[b], 0));
+        HG_HIP(hipMemcpyAsync(rep.dx[b].p, rep.hx[b], (size_t)m * in_dim * ss, hipMemcpyHostToDevice, rep.copy));
+        HG_HIP(hipEventRecord(rep.ev_h2d[b], rep.copy));
+        // ---- compute stream: kernels, features back
+        HG_HIP(hipStreamWaitEvent(rep.compute, rep.ev_h2d[b], 0));
+        run_on_device(f, rep.dx[b].p, sent_dtype, m, in_dim, rep.dy[b].p, y_dtype, y_cols, y_cols, rep.compute, &rep);
+        HG_HIP(hipMemcpyAsync(rep.hy[b], rep.dy[b].p, (size_t)m * y_cols * ys, hipMemcpyDeviceToHost, rep.compute));
+        HG_HIP(hipEventRecord(rep.ev_out[b], rep.compute));
+    }
+    if (n_chunks >= 2) unpack(n_chunks - 2);
+    unpack(n_chunks - 1);
+}
+
 }  // namespace
 
 extern "C" {
@@ -132,6 +373,7 @@ int hg_flow_load(const void* blob, size_t nbytes, int flags, hg_flow** out) {
         auto f = std::make_unique<hg_flow>();
         f->root = hg::parse_blob(blob, nbytes);
         f->flops = hg::tree_flops(*f->root);
+        f->force_generic = flags & 1;
         if (!(flags & 1)) f->exec = hg::make_fused_executor(*f->root, &f->fused_reject);
         else f->fused_reject = "generic plan forced by caller";
         if (!f->exec) f->exec = hg::make_generic_executor(*f->root);
@@ -190,11 +432,7 @@ int hg_flow_to_device(hg_flow* f, int device) {
         if (device < 0 || device >= count) hg::fail(HG_ERR_DEVICE, "device %d out of range (0..%d)", device, count - 1);
         if (f->device >= 0 && f->device != device) hg::fail(HG_ERR_STATE, "flow already lives on device %d", f->device);
         if (f->device == device) return;
-        HG_HIP(hipSetDevice(device));
-        f->exec->to_device();
-        HG_HIP(hipStreamCreateWithFlags(&f->own_stream, hipStreamNonBlocking));
-        HG_HIP(hipDeviceSynchronize());
-        f->device = device;
+        f->main.create(device);
     });
 }
 
@@ -225,27 +463,67 @@ int hg_flow_execute(hg_flow* f, const void* x, int x_dtype, int64_t n, int64_t l
         f->need_device();
         f->set_device();
         if (n == 0) return;
-        const size_t xs = hg::dtype_size(x_dtype), ys = hg::dtype_size(y_dtype);
-        const int64_t in_dim = f->root->in_dim;
-        // Row chunks of <= 256 MiB of input keep the staging buffers and activation workspace bounded.
-        int64_t chunk = std::max<int64_t>(16, (256ll << 20) / (in_dim * (int64_t)xs));
-        chunk = std::min(chunk, n);
-        chunk = (chunk + 15) / 16 * 16;
-        f->stage_x.alloc((size_t)chunk * in_dim * xs);
-        f->stage_y.alloc((size_t)chunk * y_cols * ys);
-        f->exec->reserve(chunk);
-        hipStream_t st = f->own_stream;
-        for (int64_t r0 = 0; r0 < n; r0 += chunk) {
-            const int64_t m = std::min(chunk, n - r0);
-            const char* xsrc = (const char*)x + (size_t)r0 * ldx * xs;
-            HG_HIP(hipMemcpy2DAsync(f->stage_x.p, (size_t)in_dim * xs, xsrc, (size_t)ldx * xs, (size_t)in_dim * xs, (size_t)m,
-                                    hipMemcpyHostToDevice, st));
-            run_on_device(f, f->stage_x.p, x_dtype, m, in_dim, f->stage_y.p, y_dtype, y_cols, y_cols, st);
-            char* ydst = (char*)y + (size_t)r0 * ldy * ys;
-            HG_HIP(hipMemcpy2DAsync(ydst, (size_t)ldy * ys, f->stage_y.p, (size_t)y_cols * ys, (size_t)y_cols * ys, (size_t)m,
-                                    hipMemcpyDeviceToHost, st));
-            HG_HIP(hipStreamSynchronize(st));
+        run_host_rows(f, f->main, x, x_dtype, n, ldx, y, y_dtype, y_cols, ldy, true);
+    });
+}
+
+int hg_flow_execute_sharded(hg_flow* f, const void* x, int x_dtype, int64_t n, int64_t ldx, void* y, int y_dtype, int64_t y_cols,
+                            int64_t ldy, const int* devices, int n_devices) {
+    return guarded([&] {
+        check_exec_args(f, x, x_dtype, n, ldx, y, y_dtype, y_cols, ldy);
+        if (n_devices <= 0 || n_devices > 64) hg::fail(HG_ERR_ARG, "n_devices %d outside 1..64", n_devices);
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+            hg::fail(HG_ERR_DEVICE, "no HIP device available (this library has no CPU execution path)");
+        std::vector<int> devs(n_devices);
+        for (int r = 0; r < n_devices; ++r) {
+            devs[r] = devices ? devices[r] : r;
+            if (devs[r] < 0 || devs[r] >= count) hg::fail(HG_ERR_DEVICE, "shard %d: device %d out of range (0..%d)", r, devs[r], count - 1);
         }
+        if (n == 0) return;
+        // replicas: one executor + streams + staging per listed device (a device may be listed more than once)
+        if ((int)f->shards.size() > n_devices) {
+            for (size_t r = n_devices; r < f->shards.size(); ++r) f->shards[r]->destroy();
+            f->shards.resize(n_devices);
+        }
+        while ((int)f->shards.size() < n_devices) f->shards.emplace_back(new Replica());
+        for (int r = 0; r < n_devices; ++r) {
+            Replica& rep = *f->shards[r];
+            if (rep.device == devs[r]) continue;
+            rep.destroy();
+            std::string why;
+            if (!f->force_generic) rep.exec = hg::make_fused_executor(*f->root, &why);
+            if (!rep.exec) rep.exec = hg::make_generic_executor(*f->root);
+            rep.create(devs[r]);
+        }
+        // contiguous row blocks of ceil(n / n_devices) rows (pyfaceanalysis_amd/sharded.py shard_bounds), one host thread per
+        // block; every block lands in the caller's y at its own rows, which IS the gather (host memory, no peer copy)
+        const int64_t per = (n + n_devices - 1) / n_devices;
+        const size_t xs = hg::dtype_size(x_dtype), ys = hg::dtype_size(y_dtype);
+        std::vector<std::string> errs(n_devices);
+        std::vector<int> codes(n_devices, HG_OK);
+        std::vector<std::thread> th;
+        for (int r = 0; r < n_devices; ++r) {
+            const int64_t lo = std::min<int64_t>((int64_t)r * per, n), hi = std::min<int64_t>(lo + per, n);
+            if (hi <= lo) continue;
+            th.emplace_back([&, r, lo, hi] {
+                try {
+                    Replica& rep = *f->shards[r];
+                    HG_HIP(hipSetDevice(rep.device));
+                    run_host_rows(f, rep, (const char*)x + (size_t)lo * ldx * xs, x_dtype, hi - lo, ldx, (char*)y + (size_t)lo * ldy * ys,
+                                  y_dtype, y_cols, ldy, n_devices == 1);
+                } catch (const hg::Error& e) {
+                    codes[r] = e.code;
+                    errs[r] = e.what();
+                } catch (const std::exception& e) {
+                    codes[r] = HG_ERR_STATE;
+                    errs[r] = e.what();
+                }
+            });
+        }
+        for (auto& t : th) t.join();
+        for (int r = 0; r < n_devices; ++r)
+            if (codes[r] != HG_OK) hg::fail(codes[r], "shard %d (device %d): %s", r, devs[r], errs[r].c_str());
     });
 }
 

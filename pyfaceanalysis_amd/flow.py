@@ -115,7 +115,7 @@ class Flow(object):
         return self.flow[-1].output_dim
 
     # --- native handle management -------------------------------------------------------------
-    def _handle(self, nodenr=None):
+    def _handle(self, nodenr=None, on_device=True):
         key = len(self.flow) - 1 if nodenr is None else int(nodenr)
         if not 0 <= key < len(self.flow):
             raise ValueError("nodenr %r out of range for a flow of %d nodes" % (nodenr, len(self.flow)))
@@ -124,7 +124,7 @@ class Flow(object):
             blob = self.to_blob() if key == len(self.flow) - 1 else flow_to_blob(self.flow[:key + 1])
             h = _Handle(blob, self.force_generic)
             self._handles[key] = h
-        if h.device < 0:
+        if on_device and h.device < 0:
             h.to_device(self.device)
         return h
 
@@ -144,7 +144,7 @@ class Flow(object):
             h.close()
 
     # --- the hot call -----------------------------------------------------------------------------
-    def execute(self, x, nodenr=None, benchmark=None, n_cols=None):
+    def execute(self, x, nodenr=None, benchmark=None, n_cols=None, devices=None):
         """Process ``x`` (N, input_dim) through the nodes up to ``nodenr`` (all by default).
 
         ``benchmark``: object with the reference's Benchmark interface (benchmarking.py:39-58);
@@ -152,6 +152,8 @@ class Flow(object):
         ``add_task_ellapsed(label, seconds, reference)`` like cuicuilco's patched ``_execute_seq``.
         ``n_cols`` (extension): return only the first n_cols features — the caller consumes
         ``sl[:, 0:classifier.input_dim]`` (FaceDetectUpdated.py:709,719).
+        ``devices`` (extension): list of HIP device ordinals; the rows are cut into len(devices) contiguous
+        blocks that run concurrently, one replica of the weights per entry (``hg_flow_execute_sharded``).
         """
         x = np.asarray(x)
         if x.ndim != 2:
@@ -161,7 +163,7 @@ class Flow(object):
         if nodenr is not None and not 0 <= int(nodenr) < len(self.flow):
             raise ValueError("nodenr %r out of range for a flow of %d nodes" % (nodenr, len(self.flow)))
         out_dim = self.flow[len(self.flow) - 1 if nodenr is None else nodenr].output_dim
-        h = self._handle(nodenr)
+        h = self._handle(nodenr, on_device=devices is None)
         code = _capi.np_dtype_code(x.dtype)
         if code is None:
             x = x.astype(np.float64)
@@ -182,6 +184,11 @@ class Flow(object):
         if prof:
             _capi.check(L.hg_flow_reset_profile(h.h))
         _capi.check(L.hg_flow_set_profiling(h.h, 1 if prof else 0))
+        if devices is not None:
+            devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+            _capi.check(L.hg_flow_execute_sharded(h.h, x.ctypes.data_as(C.c_void_p), code, n, ldx, y.ctypes.data_as(C.c_void_p),
+                                                  _capi.np_dtype_code(y.dtype), cols, cols, devs, len(devices)))
+            return y
         _capi.check(L.hg_flow_execute(h.h, x.ctypes.data_as(C.c_void_p), code, n, ldx,
                                       y.ctypes.data_as(C.c_void_p), _capi.np_dtype_code(y.dtype), cols, cols))
         if prof:

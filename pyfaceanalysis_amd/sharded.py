@@ -1,14 +1,18 @@
-"""Row-sharded execution over the GPUs of one node.
+"""Row-sharded execution over the GPUs of one node, one process per GPU.
 
 Every sub-image is independent (no cross-row term in any node; the caller's compaction,
 FaceDetectUpdated.py:739-759, is per-row masking), so rank r of W takes the contiguous row block
 ``[r*ceil(N/W), ...)``, weights are replicated, and there is no exchange inside the 11 layers.
 The only collective is the one the caller needs: an all-gather of the first k slow features
 (``torch.distributed`` backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests).
+
+``ShardedFlow`` is device-resident: the rank's block and the gathered features are torch tensors on
+the rank's device, nothing passes through numpy or the host.  ``bench.py`` times exactly
+``ShardedFlow.step``; ``tests/test_sharded_gloo.py`` runs the same class at world size 2 over gloo with
+a CPU compute callable.  (A single process driving several GPUs uses the C entry
+``hg_flow_execute_sharded`` instead — host buffers in and out, no collective.)
 """
 from __future__ import annotations
-
-import numpy as np
 
 
 def shard_bounds(n_rows, world, rank):
@@ -29,39 +33,100 @@ def gather_features(y_local, y_all):
 
 
 class ShardedFlow(object):
-    """``execute(x)`` over all ranks of the default process group: every rank passes the same
-    global ``x`` (or only its shard with ``x_is_local=True``) and receives the full (N, k) result.
+    """One rank's share of a sharded ``flow.execute``.
 
-    ``execute_local`` is the per-rank compute callable ``(x_block ndarray) -> (rows, k) ndarray``;
-    in production it is ``Flow.execute`` bound to this rank's GPU.  It is injected so that the
-    sharding/gather logic can be exercised on CPU ranks (gloo) with any callable.
+    ``execute_local(x_block, y_out, stream)`` is the per-rank compute: it reads the (m, input_dim) tensor
+    ``x_block`` and writes the first ``n_cols`` features of every row into the (m, n_cols) float32 tensor
+    ``y_out``, enqueued on the raw stream handle ``stream`` (0 on CPU).  In production it is
+    ``Flow.execute_device`` on this rank's GPU (``ShardedFlow.for_flow``); the CPU tests inject a callable.
+
+    ``rows`` is the block size ceil(N / world) every rank allocates for; a rank may pass fewer rows
+    (the last block of a ragged batch), the rest of its block stays zero.
+    ``collective``: issue the all-gather (default: whenever a process group is initialised).
+
+    On a GPU the gather of step i runs on a side stream under the kernels of step i+1 (two feature
+    buffers, events in both directions); ``step`` returns the tensor the gather writes, valid once
+    ``wait()`` (or the returned tensor's stream dependencies) has been honoured.
     """
 
-    def __init__(self, execute_local, n_cols, device=None):
-        self.execute_local = execute_local
-        self.n_cols = int(n_cols)
-        self.device = device
-
-    def execute(self, x, x_is_local=False, n_total=None):
+    def __init__(self, execute_local, n_cols, rows, device=None, collective=None):
         import torch
         import torch.distributed as dist
-        world, rank = dist.get_world_size(), dist.get_rank()
-        if x_is_local:
-            if n_total is None:
-                raise ValueError("n_total is required with x_is_local=True")
-            lo, hi, per = shard_bounds(n_total, world, rank)
-            xb = x
-            if xb.shape[0] != hi - lo:
-                raise ValueError("rank %d: local block has %d rows, expected %d" % (rank, xb.shape[0], hi - lo))
+        self.torch = torch
+        self.execute_local = execute_local
+        self.n_cols, self.rows = int(n_cols), int(rows)
+        self.device = torch.device("cpu") if device is None else torch.device(device)
+        self.cuda = self.device.type == "cuda"
+        have_pg = dist.is_available() and dist.is_initialized()
+        self.collective = have_pg if collective is None else bool(collective)
+        if self.collective and not have_pg:
+            raise RuntimeError("ShardedFlow: collective requested but no process group is initialised")
+        self.world = dist.get_world_size() if self.collective else 1
+        self.rank = dist.get_rank() if self.collective else 0
+        mk = lambda r: torch.zeros((r, self.n_cols), dtype=torch.float32, device=self.device)
+        self.ys = [mk(self.rows), mk(self.rows)]
+        self.y_alls = [mk(self.rows * self.world), mk(self.rows * self.world)] if self.collective else None
+        self._n = 0
+        if self.cuda:
+            self.stream = torch.cuda.current_stream(self.device)
+            self.comm = torch.cuda.Stream(self.device) if self.collective else None
+            self.gathered = [torch.cuda.Event(), torch.cuda.Event()]
+
+    @classmethod
+    def for_flow(cls, flow, n_cols, rows, device, collective=None):
+        """Bind ``flow.execute_device`` (pyfaceanalysis_amd.flow.Flow on this rank's GPU)."""
+        import numpy as np
+        import torch
+        np_dt = {torch.float32: np.float32, torch.float64: np.float64, torch.uint8: np.uint8}
+        flow.reserve(rows)
+
+        def run(x_block, y_out, stream):
+            if x_block.stride(1) != 1 or y_out.stride() != (n_cols, 1):
+                raise ValueError("ShardedFlow: x rows and the feature buffer must be contiguous")
+            flow.execute_device(x_block.data_ptr(), np_dt[x_block.dtype], x_block.shape[0], x_block.stride(0),
+                                y_out.data_ptr(), np.float32, n_cols, n_cols, stream=stream)
+        return cls(run, n_cols, rows, device=device, collective=collective)
+
+    def step(self, x_local):
+        """Enqueue one pass over this rank's block; returns the (world*rows, n_cols) gathered features
+        (or the (rows, n_cols) local ones without a collective) of THIS step."""
+        torch = self.torch
+        b = self._n & 1
+        self._n += 1
+        m = int(x_local.shape[0])
+        if m > self.rows:
+            raise ValueError("rank %d: local block has %d rows, more than the %d allocated" % (self.rank, m, self.rows))
+        if self.cuda and self.collective:
+            self.stream.wait_event(self.gathered[b])      # the gather that read ys[b] two steps ago is done
+        if m:
+            self.execute_local(x_local, self.ys[b][:m], self.stream.cuda_stream if self.cuda else 0)
+        if not self.collective:
+            return self.ys[b]
+        if self.cuda:
+            done = torch.cuda.Event()
+            done.record(self.stream)
+            self.comm.wait_event(done)
+            with torch.cuda.stream(self.comm):
+                gather_features(self.ys[b], self.y_alls[b])
+                self.gathered[b].record(self.comm)
         else:
-            n_total = x.shape[0]
-            lo, hi, per = shard_bounds(n_total, world, rank)
-            xb = x[lo:hi]
-        yb = np.zeros((per, self.n_cols), dtype=np.float32)
-        if hi > lo:
-            yb[:hi - lo] = np.asarray(self.execute_local(xb))[:, :self.n_cols]
-        dev = self.device if self.device is not None else "cpu"
-        y_local = torch.from_numpy(yb).to(dev)
-        y_all = torch.empty((per * world, self.n_cols), dtype=torch.float32, device=dev)
-        gather_features(y_local, y_all)
-        return y_all[:n_total].cpu().numpy()
+            gather_features(self.ys[b], self.y_alls[b])
+        return self.y_alls[b]
+
+    def wait(self):
+        """Block until everything enqueued so far (kernels and gathers) is complete."""
+        if self.cuda:
+            self.torch.cuda.synchronize(self.device)
+
+    def execute(self, x_local, n_total=None):
+        """Synchronous form: the (n_total, n_cols) features of the whole batch, on this rank's device.
+        ``x_local`` is this rank's block (``shard_bounds``); n_total defaults to rows * world."""
+        y = self.step(x_local)
+        self.wait()
+        n_total = self.rows * self.world if n_total is None else int(n_total)
+        lo, hi, per = shard_bounds(n_total, self.world, self.rank)
+        if (self.world > 1 and per != self.rows) or per > self.rows:       # rank r's rows sit at r * self.rows in the gathered matrix
+            raise ValueError("n_total %d does not match blocks of %d rows on %d ranks" % (n_total, self.rows, self.world))
+        if int(x_local.shape[0]) != hi - lo:
+            raise ValueError("rank %d: local block has %d rows, expected %d" % (self.rank, x_local.shape[0], hi - lo))
+        return y[:n_total]

@@ -186,6 +186,34 @@ def test_flow_container_protocol(nets):
         Flow([])
 
 
+def test_sharded_entry_argument_checks(native_lib, nets):
+    """hg_flow_execute_sharded validates like hg_flow_execute before touching any device, then needs one."""
+    b = blob.flow_to_blob(nets("T3L-8"))
+    rc, h = _load(native_lib, b)
+    assert rc == 0
+    x = np.zeros((4, 64))
+    y = np.zeros((4, 6))
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    call = lambda *a: native_lib.hg_flow_execute_sharded(h, *a)
+    devs = (C.c_int * 2)(0, 0)
+    assert call(vp(x), _capi.HG_F64, 4, 64, vp(y), _capi.HG_F64, 6, 6, devs, 0) == _capi.HG_ERR_ARG          # no devices
+    assert call(vp(x), _capi.HG_F64, 4, 64, vp(y), _capi.HG_F64, 6, 6, devs, 65) == _capi.HG_ERR_ARG
+    assert call(vp(x), _capi.HG_F64, 4, 63, vp(y), _capi.HG_F64, 6, 6, devs, 2) == _capi.HG_ERR_DIM           # ldx < input_dim
+    assert call(vp(x), _capi.HG_F64, 4, 64, vp(y), _capi.HG_F64, 7, 7, devs, 2) == _capi.HG_ERR_DIM           # y_cols > output_dim
+    assert call(vp(x), 7, 4, 64, vp(y), _capi.HG_F64, 6, 6, devs, 2) == _capi.HG_ERR_ARG                      # dtype
+    assert call(None, _capi.HG_F64, 4, 64, vp(y), _capi.HG_F64, 6, 6, devs, 2) == _capi.HG_ERR_ARG            # null x
+    assert call(vp(x), _capi.HG_F64, -1, 64, vp(y), _capi.HG_F64, 6, 6, devs, 2) == _capi.HG_ERR_ARG
+    cnt = C.c_int(-1)
+    native_lib.hg_device_count(C.byref(cnt))
+    if cnt.value == 0:
+        assert call(vp(x), _capi.HG_F64, 4, 64, vp(y), _capi.HG_F64, 6, 6, devs, 2) == _capi.HG_ERR_DEVICE
+        assert b"no HIP device" in native_lib.hg_last_error()
+    else:
+        bad = (C.c_int * 1)(cnt.value)
+        assert call(vp(x), _capi.HG_F64, 4, 64, vp(y), _capi.HG_F64, 6, 6, bad, 1) == _capi.HG_ERR_DEVICE
+    native_lib.hg_flow_free(h)
+
+
 def test_no_gpu_means_loud_failure(native_lib, nets):
     cnt = C.c_int(-1)
     assert native_lib.hg_device_count(C.byref(cnt)) == 0
@@ -194,6 +222,8 @@ def test_no_gpu_means_loud_failure(native_lib, nets):
     f = Flow(nets("T3L-8"))
     with pytest.raises(RuntimeError, match="no HIP device"):
         f.execute(np.zeros((2, 64)))
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        f.execute(np.zeros((2, 64)), devices=[0, 1])
     from pyfaceanalysis_amd.classifier import GaussianClassifier
     g = GaussianClassifier(np.zeros((2, 3)), np.stack([np.eye(3)] * 2), np.ones(2), np.ones(2) / 2, avg_labels=[0.0, 1.0])
     with pytest.raises(RuntimeError, match="no HIP device"):

@@ -1,6 +1,7 @@
 """CPU, world_size 2 over gloo: the row-sharding + all-gather logic of pyfaceanalysis_amd.sharded
-(SURVEY.md §8e).  The per-rank compute callable is injected; here it is the oracle, because the
-HIP path needs a GPU — the test checks the partition/gather, not the arithmetic."""
+ — the same ``ShardedFlow.step`` that bench.py times on the GPUs.  The per-rank compute callable is
+injected; here it is the oracle, because the HIP path needs a GPU — the test checks the partition/gather, not the
+arithmetic.  Success = exit code 0 of the launcher and one result file per rank."""
 import os
 import subprocess
 import sys
@@ -15,25 +16,38 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = r"""
 import os, sys
 sys.path.insert(0, {root!r})
-import numpy as np, torch.distributed as dist
+import numpy as np, torch, torch.distributed as dist
 from oracle import mdp_restate
 from pyfaceanalysis_amd import synth
 from pyfaceanalysis_amd.sharded import ShardedFlow, shard_bounds
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 nodes = synth.build_preset("T3L-8")
-for n in (37, 1, 64):
+K = 4
+
+def run(xb, y_out, stream):          # the role Flow.execute_device plays on a GPU
+    y_out.copy_(torch.from_numpy(mdp_restate.execute_flow(nodes, xb.numpy())[:, :K].astype(np.float32)))
+
+checked = 0
+for n in (37, 1, 64, 2):
     x = synth.make_subimages(n, 8, seed=5, dtype=np.float64)
-    ref = mdp_restate.execute_flow(nodes, x)[:, :4]
-    sf = ShardedFlow(lambda xb: mdp_restate.execute_flow(nodes, xb), n_cols=4)
-    y = sf.execute(x)
-    assert y.shape == (n, 4) and np.abs(y - ref).max() <= 1e-6 * np.abs(ref).max(), (rank, n)
+    ref = mdp_restate.execute_flow(nodes, x)[:, :K]
     lo, hi, per = shard_bounds(n, world, rank)
-    y2 = sf.execute(x[lo:hi], x_is_local=True, n_total=n)
-    assert np.array_equal(y, y2)
+    sf = ShardedFlow(run, n_cols=K, rows=per)
+    assert sf.collective and sf.world == world
+    xl = torch.from_numpy(x[lo:hi])
+    y = sf.execute(xl, n_total=n)
+    assert tuple(y.shape) == (n, K) and np.abs(y.numpy() - ref).max() <= 1e-6 * np.abs(ref).max(), (rank, n)
+    # steps alternate between two buffers: three more steps give the same rows every time
+    for _ in range(3):
+        y2 = sf.step(xl)
+        sf.wait()
+        assert torch.equal(y2[:n], y)
+    checked += 1
 dist.barrier()
 dist.destroy_process_group()
-print("rank", rank, "ok")
+with open(os.path.join({out!r}, "rank%d.ok" % rank), "w") as fh:
+    fh.write("%d\n" % checked)
 """
 
 
@@ -49,22 +63,34 @@ def test_shard_bounds():
     assert covered == list(range(37))
 
 
+def test_single_process_without_collective():
+    """No process group: ShardedFlow degrades to the local pass (what `python bench.py` runs at N = 1)."""
+    import torch
+    from pyfaceanalysis_amd.sharded import ShardedFlow
+    calls = []
+
+    def run(xb, y_out, stream):
+        calls.append(int(xb.shape[0]))
+        y_out.copy_(xb[:, :3].float() * 2)
+    sf = ShardedFlow(run, n_cols=3, rows=8)
+    assert not sf.collective and sf.world == 1
+    x = torch.arange(40, dtype=torch.float64).reshape(8, 5)
+    assert torch.equal(sf.execute(x), x[:, :3].float() * 2)
+    assert torch.equal(sf.execute(x[:5], n_total=5), x[:5, :3].float() * 2) and calls == [8, 5]
+    with pytest.raises(ValueError):
+        sf.step(torch.zeros(9, 5))
+
+
 def test_world_size_2_gloo(tmp_path):
-    import socket
     script = tmp_path / "worker.py"
-    script.write_text(WORKER.format(root=ROOT))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
-    out = ""
-    for attempt in range(3):                          # rendezvous can lose a port race on a busy box: retry on a fresh port
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-               "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
-        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
-        out = r.stdout.decode(errors="replace")
-        if r.returncode == 0 and "rank 0 ok" in out and "rank 1 ok" in out:
-            return
-        if "AssertionError" in out:                   # a real numerical / logic failure: do not retry
-            break
-    raise AssertionError(out[-3000:])
+    script.write_text(WORKER.format(root=ROOT, out=str(tmp_path)))
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    # --standalone: the launcher picks a free rendezvous port itself (no port race to retry around)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node=2", str(script)]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode == 0, out[-3000:]
+    for rank in range(2):
+        f = tmp_path / ("rank%d.ok" % rank)
+        assert f.exists() and f.read_text().strip() == "4", out[-3000:]
