@@ -151,7 +151,11 @@ int hg_gauss_regression(hg_gauss* g, const void* x, int x_dtype, int64_t n, int6
  * The producer of the hot call's input: load_network_subimages -> extract_subimages_rotate
  * (face_analysis.py:775-800; FaceDetectUpdated.py:686), which crops every window with PIL's
  * Image.transform((w, h), EXTENT, (x0, y0, x1, y1), NEAREST).  Same index rule, bit for bit
- * (tested against PIL); rotation angles other than 0 are not covered.
+ * (tested against PIL).  The *_rotate entries also take delta_angs (degrees, counter-clockwise, the
+ * reference passes -1 * curr_angles, face_analysis.py:782; null = no rotation): a window with
+ * delta_ang != 0 is cut from frame.rotate(delta_ang, NEAREST, center = centre of its box) — PIL's
+ * Image.rotate arithmetic (16.16 fixed point), composed with the EXTENT rule per pixel; cuicuilco's own
+ * composition is not available, this rule is the build's and is tested against PIL.
  * frame: (frame_h, frame_w) pixels, HG_U8 or HG_F32, row stride ld elements.  boxes: n x 4 doubles
  * (x0, y0, x1, y1) in frame coordinates.  out: n rows of out_w*out_h elements (row-major pixels,
  * the layout flow.execute expects), row stride ldo elements, dtype U8 / F32 / F64. */
@@ -164,6 +168,41 @@ int hg_patcher_extract_device(hg_patcher* p, const void* frame_dev, int frame_dt
 int hg_patcher_extract(hg_patcher* p, const void* frame, int frame_dtype, int frame_h, int frame_w, int64_t ld,
                        const double* boxes, int64_t n, int out_w, int out_h, void* out, int out_dtype,
                        int64_t ldo);
+int hg_patcher_extract_rotate_device(hg_patcher* p, const void* frame_dev, int frame_dtype, int frame_h, int frame_w,
+                                     int64_t ld, const double* boxes_dev, const double* delta_angs_dev, int64_t n,
+                                     int out_w, int out_h, void* out_dev, int out_dtype, int64_t ldo, void* stream);
+int hg_patcher_extract_rotate(hg_patcher* p, const void* frame, int frame_dtype, int frame_h, int frame_w, int64_t ld,
+                              const double* boxes, const double* delta_angs, int64_t n, int out_w, int out_h,
+                              void* out, int out_dtype, int64_t ldo);
+
+/* --- Cascade glue on the device (the reference's stage loop between two hot calls) -----------------
+ * update_current_subimage_coordinates (face_analysis.py:803-840) + identify_patches_to_discard (:842-887) for n
+ * candidates from their regression outputs, then the boolean-mask compaction of FaceDetectUpdated.py:739-759 as
+ * "index map + row gather", so that extract -> execute -> regression -> update -> discard -> compaction chain on one
+ * stream.  float64, the reference's operation order.  Candidates of all pyramid levels may share a batch: the per-level
+ * constants travel per ORIGINAL window in orig_level (n0, 3) = (max_Dx_diff, max_Dy_diff, base_side),
+ * FaceDetectUpdated.py:595,604-605; orig_index maps a candidate to its original window (:621). */
+enum hg_stage_type { HG_STAGE_DISC = 0, HG_STAGE_POSX = 1, HG_STAGE_POSY = 2, HG_STAGE_PANG = 3, HG_STAGE_SCALE = 4 };
+typedef struct hg_cascade_consts {
+    double regression_width, regression_height;   /* Pipeline header (face_analysis.py:395-400)            */
+    double desired_sampling;                      /* 0.825 (FaceDetectUpdated.py:729)                        */
+    double tolerance_posxy_deviation, tolerance_scale_deviation, tolerance_angle_deviation; /* :113-115      */
+    double max_scale_radio, min_scale_radio;      /* net_maxs / 0.825, net_mins / 0.825 (:596-597)           */
+    double net_Dang;
+    double cut_off_face;                          /* cut_offs_face[network_serial] (:98, :672), Disc stages  */
+} hg_cascade_consts;
+/* coords (n,4) and angles (n) are updated in place; discard[i] = 1 where the reference sets new_wrong_images. */
+int hg_cascade_update_device(int device, int stage_type, const hg_cascade_consts* c, int64_t n, double* coords_dev,
+                             double* angles_dev, const double* reg_dev, const int32_t* orig_index_dev,
+                             const double* orig_coords_dev, const double* orig_angles_dev, const double* orig_level_dev,
+                             uint8_t* discard_dev, void* stream);
+/* map_dev[j] = index of the j-th candidate with discard == 0 (order kept), *count_dev = how many. */
+int hg_cascade_compact_device(int device, const uint8_t* discard_dev, int64_t n, int32_t* map_dev, int32_t* count_dev,
+                              void* stream);
+/* dst[j, :] = src[map[j], :] for j < *count_dev (count read on the device); rows of row_bytes bytes (multiple of 4);
+ * n_max bounds the launch (the candidate count before compaction).  Out of place. */
+int hg_gather_rows_device(int device, const void* src_dev, void* dst_dev, int64_t row_bytes, const int32_t* map_dev,
+                          const int32_t* count_dev, int64_t n_max, void* stream);
 
 /* --- SFA training step for one layer of nodes (BASELINE.json configs[4]) -----
  * Not on the reference's path (it never trains, face_analysis.py:451-479); restates

@@ -23,6 +23,15 @@ class HgInfo(C.Structure):
                 ("padded_flops_per_row", C.c_int64), ("workspace_bytes", C.c_int64)]
 
 
+class HgCascadeConsts(C.Structure):
+    _fields_ = [(n, C.c_double) for n in (
+        "regression_width", "regression_height", "desired_sampling", "tolerance_posxy_deviation", "tolerance_scale_deviation",
+        "tolerance_angle_deviation", "max_scale_radio", "min_scale_radio", "net_Dang", "cut_off_face")]
+
+
+HG_STAGE = {"Disc": 0, "PosX": 1, "PosY": 2, "PAng": 3, "Scale": 4}
+
+
 class NativeLibraryMissing(ImportError):
     pass
 
@@ -68,6 +77,11 @@ def lib():
         "hg_patcher_free": (None, [vp]),
         "hg_patcher_extract_device": (C.c_int, [vp, vp, i32, i32, i32, i64, vp, i64, i32, i32, vp, i32, i64, vp]),
         "hg_patcher_extract": (C.c_int, [vp, vp, i32, i32, i32, i64, vp, i64, i32, i32, vp, i32, i64]),
+        "hg_patcher_extract_rotate_device": (C.c_int, [vp, vp, i32, i32, i32, i64, vp, vp, i64, i32, i32, vp, i32, i64, vp]),
+        "hg_patcher_extract_rotate": (C.c_int, [vp, vp, i32, i32, i32, i64, vp, vp, i64, i32, i32, vp, i32, i64]),
+        "hg_cascade_update_device": (C.c_int, [i32, i32, C.POINTER(HgCascadeConsts), i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+        "hg_cascade_compact_device": (C.c_int, [i32, vp, i64, vp, vp, vp]),
+        "hg_gather_rows_device": (C.c_int, [i32, vp, vp, i64, vp, vp, i64, vp]),
         "hg_sfa_train_layer": (C.c_int, [vp, i32, i32, i64, i64, vp, C.c_int32, C.c_int32, i32, vp, vp, vp, vp]),
     }
     for name, (res, args) in sigs.items():
@@ -84,7 +98,8 @@ EXPORTED_SYMBOLS = (
     "hg_flow_execute_device", "hg_flow_set_profiling", "hg_flow_stage_times", "hg_flow_stage_name",
     "hg_flow_reset_profile", "hg_gauss_create", "hg_gauss_free", "hg_gauss_regression_device",
     "hg_gauss_regression", "hg_patcher_create", "hg_patcher_free", "hg_patcher_extract_device",
-    "hg_patcher_extract", "hg_sfa_train_layer",
+    "hg_patcher_extract", "hg_patcher_extract_rotate_device", "hg_patcher_extract_rotate", "hg_cascade_update_device",
+    "hg_cascade_compact_device", "hg_gather_rows_device", "hg_sfa_train_layer",
 )
 
 _EXC = {HG_ERR_ARG: ValueError, HG_ERR_FORMAT: ValueError, HG_ERR_DIM: ValueError,

@@ -72,6 +72,15 @@ class GaussianClassifier(object):
                 reg.ctypes.data_as(C.c_void_p), sd.ctypes.data_as(C.c_void_p) if estimate_std else None))
         return (reg, sd) if estimate_std else reg
 
+    def regression_device(self, x_ptr, x_dtype, n, ldx, out_reg_ptr, out_std_ptr=None, stream=0, avg_labels=None):
+        """Device-resident form (raw pointers, enqueued on ``stream``): reads the first ``input_dim`` columns of the
+        (n, ldx) feature matrix — the caller's ``sl[:, 0:reg_num_signals]`` (FaceDetectUpdated.py:719) — and writes n
+        float64 regression outputs."""
+        h = self._handle(self.avg_labels if avg_labels is None else avg_labels)
+        _capi.check(_capi.lib().hg_gauss_regression_device(
+            h, C.c_void_p(x_ptr), _capi.np_dtype_code(x_dtype), int(n), int(ldx), C.c_void_p(out_reg_ptr),
+            C.c_void_p(out_std_ptr) if out_std_ptr else None, C.c_void_p(stream)))
+
     def close(self):
         if self._h is not None:
             _capi.lib().hg_gauss_free(self._h)

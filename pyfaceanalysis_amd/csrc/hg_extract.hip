@@ -6,15 +6,27 @@
 // EXTENT/NEAREST index rule (ImagingScaleAffine) exactly, including its additive accumulation of the
 // source coordinate in double precision:
 //     a = (x1 - x0) / w;  xo = x0 + a/2;  for x in 0..w-1: xin = xo < 0 ? -1 : (int)xo;  xo += a
-// (same for y); source pixels outside the frame leave the output pixel 0.  Angles other than 0 are not
-// covered (the rotation rule lives in cuicuilco, which is not available): callers must pass boxes only.
+// (same for y); source pixels outside the frame leave the output pixel 0.
+//
+// Rotated windows (delta_ang != 0; the reference passes -1 * curr_angles, face_analysis.py:782, non-zero after the first
+// PAng stage).  cuicuilco's own composition is not available ([K]); the rule implemented — and tested bit for bit
+// against PIL — is
+//     window = frame.rotate(delta_ang, NEAREST, center = ((x0 + x1) / 2, (y0 + y1) / 2)).transform((w, h), EXTENT, box, NEAREST)
+// composed per output pixel: the EXTENT tables give the pixel (xr, yr) of the ROTATED frame, and PIL's affine_fixed()
+// (Geometry.c) gives that pixel's source: 16.16 fixed-point coefficients A0..A5 from the matrix Image.rotate builds
+// (cos / sin of -radians(angle % 360) rounded to 15 decimals), xs = (A2 + yr A1 + xr A0) >> 16, ys likewise.  The integer
+// sums are PIL's running sums in closed form.  Multiples of 180 degrees take PIL's "scaling" branch (sin rounds to 0) with
+// its floating running sums.  The coefficients are computed on the device in double precision without contraction; the
+// one place this can differ from the host's libm is the last bit of cos / sin before the 15-decimal rounding, which
+// moves a fixed-point coefficient only if it sits within 7e-11 of a rounding boundary.  Rotated frames must stay inside
+// PIL's fixed-point range (|source coordinate| < 32768), otherwise the window is left 0.
 #include <hip/hip_runtime.h>
 
 #include "hg_common.hpp"
 
 struct hg_patcher {
     int device = -1;
-    hg::DevBuf tabs, boxes, frame, out;
+    hg::DevBuf tabs, boxes, frame, out, rot, angles;
 };
 
 namespace hg { void set_last_error(const std::string& s); }
@@ -83,6 +95,103 @@ __global__ void __launch_bounds__(256) k_extent_gather(const FT* __restrict__ fr
     }
 }
 
+// Per-box rotation record (Image.rotate's matrix as affine_fixed / ImagingScaleAffine use it).
+struct RotCoef {
+    int32_t mode;            // 0: no rotation, 1: fixed point, 2: scaling branch (sin rounds to 0), 3: outside the fixed-point range
+    int32_t A[6];
+    int32_t pad;
+    double m0, m2, m4, m5;   // scaling branch
+};
+
+__device__ __forceinline__ double round15(double v) {       // Python round(v, 15) for |v| <= 1
+    return __ddiv_rn(rint(__dmul_rn(v, 1e15)), 1e15);
+}
+__device__ __forceinline__ int32_t fix16(double v) {        // Geometry.c FIX(): FLOOR(v * 65536 + 0.5)
+    const double x = __dadd_rn(__dmul_rn(v, 65536.0), 0.5);
+    return x >= 0.0 ? (int32_t)x : (int32_t)floor(x);
+}
+
+__global__ void k_rot_coefs(const double* __restrict__ boxes, const double* __restrict__ angs, int64_t n, int fw, int fh,
+                            RotCoef* __restrict__ out) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n) return;
+    RotCoef rc{};
+    double a = fmod(angs[b], 360.0);                 // Python's float %: result carries the divisor's sign
+    if (a < 0.0) a += 360.0;
+    if (a == 360.0) a = 0.0;
+    if (a != 0.0 && isfinite(a)) {
+        const double cx = __dmul_rn(__dadd_rn(boxes[b * 4], boxes[b * 4 + 2]), 0.5), cy = __dmul_rn(__dadd_rn(boxes[b * 4 + 1], boxes[b * 4 + 3]), 0.5);
+        const double r = -__dmul_rn(a, 3.14159265358979323846 / 180.0);       // -math.radians(angle)
+        const double c = round15(cos(r)), sn = round15(sin(r));
+        const double m0 = c, m1 = sn, m3 = -sn, m4 = c;
+        // transform(-cx, -cy, matrix) = (a x + b y) + c, then += center: every operation rounded on its own
+        const double m2 = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(m0, -cx), __dmul_rn(m1, -cy)), 0.0), cx);
+        const double m5 = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(m3, -cx), __dmul_rn(m4, -cy)), 0.0), cy);
+        if (m1 == 0.0 && m3 == 0.0) {
+            rc.mode = 2;
+            rc.m0 = m0; rc.m2 = m2; rc.m4 = m4; rc.m5 = m5;
+        } else {
+            // check_fixed() on the four corners of the rotated frame (same size as the frame)
+            bool ok = true;
+            const double xs[2] = {0.0, (double)fw}, ys[2] = {0.0, (double)fh};
+            for (int i = 0; i < 2; ++i)
+                for (int j = 0; j < 2; ++j) {
+                    const double u = __dadd_rn(__dadd_rn(__dmul_rn(xs[i], m0), __dmul_rn(ys[j], m1)), m2);
+                    const double v = __dadd_rn(__dadd_rn(__dmul_rn(xs[i], m3), __dmul_rn(ys[j], m4)), m5);
+                    ok = ok && fabs(u) < 32768.0 && fabs(v) < 32768.0;
+                }
+            rc.mode = ok ? 1 : 3;
+            rc.A[0] = fix16(m0); rc.A[1] = fix16(m1); rc.A[3] = fix16(m3); rc.A[4] = fix16(m4);
+            rc.A[2] = fix16(__dadd_rn(__dadd_rn(m2, __dmul_rn(m0, 0.5)), __dmul_rn(m1, 0.5)));
+            rc.A[5] = fix16(__dadd_rn(__dadd_rn(m5, __dmul_rn(m3, 0.5)), __dmul_rn(m4, 0.5)));
+        }
+    }
+    out[b] = rc;
+}
+
+// Rotated windows: per pixel, EXTENT table -> pixel of the rotated frame -> source pixel.  The frame (<= a few MB)
+// sits in L2; the access pattern is a rotated scan line.
+template <typename FT, typename OT>
+__global__ void __launch_bounds__(256) k_extent_gather_rot(const FT* __restrict__ frame, int64_t ld, int fw, int fh, const int32_t* __restrict__ tabs,
+                                                            const RotCoef* __restrict__ rot, int64_t n, int w, int h, OT* __restrict__ out, int64_t ldo) {
+    const int y = blockIdx.x * blockDim.y + threadIdx.y;
+    if (y >= h) return;
+    for (int64_t b = blockIdx.y; b < n; b += gridDim.y) {
+        const RotCoef rc = rot[b];
+        const int32_t* t = tabs + b * (w + h);
+        const int yr = t[w + y];
+        OT* dst = out + b * ldo + (int64_t)y * w;
+        double yo = 0.0;
+        int ys2 = -1;
+        if (rc.mode == 2 && yr >= 0) {      // ImagingScaleAffine on the rotated frame: yo = a5 + a4 / 2, then += a4 per row
+            yo = __dadd_rn(rc.m5, __dmul_rn(rc.m4, 0.5));
+            for (int k = 0; k < yr; ++k) yo = __dadd_rn(yo, rc.m4);
+            ys2 = yo < 0.0 ? -1 : (int)yo;
+            if (ys2 >= fh) ys2 = -1;
+        }
+        for (int x = threadIdx.x; x < w; x += blockDim.x) {
+            const int xr = t[x];
+            int xs = -1, ys = -1;
+            if (xr >= 0 && yr >= 0) {
+                if (rc.mode == 0) {
+                    xs = xr; ys = yr;
+                } else if (rc.mode == 1) {
+                    const int64_t xx = (int64_t)rc.A[2] + (int64_t)yr * rc.A[1] + (int64_t)xr * rc.A[0];
+                    const int64_t yy = (int64_t)rc.A[5] + (int64_t)yr * rc.A[4] + (int64_t)xr * rc.A[3];
+                    xs = (int)(xx >> 16); ys = (int)(yy >> 16);
+                } else if (rc.mode == 2) {
+                    double xo = __dadd_rn(rc.m2, __dmul_rn(rc.m0, 0.5));
+                    for (int k = 0; k < xr; ++k) xo = __dadd_rn(xo, rc.m0);
+                    xs = xo < 0.0 ? -1 : (int)xo;
+                    ys = ys2;
+                }
+            }
+            const bool in = xs >= 0 && xs < fw && ys >= 0 && ys < fh;
+            dst[x] = in ? (OT)frame[(int64_t)ys * ld + xs] : (OT)0;
+        }
+    }
+}
+
 template <typename F>
 int guarded(F&& fn) {
     try {
@@ -107,6 +216,19 @@ void launch_gather(const void* frame, int64_t ld, const int32_t* tabs, int64_t n
         case HG_U8: hipLaunchKernelGGL((k_extent_gather<FT, uint8_t>), grid, thr, 0, st, (const FT*)frame, ld, tabs, n, w, h, (uint8_t*)out, ldo); break;
         case HG_F32: hipLaunchKernelGGL((k_extent_gather<FT, float>), grid, thr, 0, st, (const FT*)frame, ld, tabs, n, w, h, (float*)out, ldo); break;
         default: hipLaunchKernelGGL((k_extent_gather<FT, double>), grid, thr, 0, st, (const FT*)frame, ld, tabs, n, w, h, (double*)out, ldo); break;
+    }
+}
+
+template <typename FT>
+void launch_gather_rot(const void* frame, int64_t ld, int fw, int fh, const int32_t* tabs, const RotCoef* rot, int64_t n, int w, int h, void* out,
+                       int out_dtype, int64_t ldo, hipStream_t st) {
+    const unsigned tx = w >= 128 ? 128 : w >= 64 ? 64 : 32;
+    const dim3 thr(tx, 256 / tx);
+    const dim3 grid((unsigned)((h + thr.y - 1) / thr.y), (unsigned)std::min<int64_t>(n, 65535));
+    switch (out_dtype) {
+        case HG_U8: hipLaunchKernelGGL((k_extent_gather_rot<FT, uint8_t>), grid, thr, 0, st, (const FT*)frame, ld, fw, fh, tabs, rot, n, w, h, (uint8_t*)out, ldo); break;
+        case HG_F32: hipLaunchKernelGGL((k_extent_gather_rot<FT, float>), grid, thr, 0, st, (const FT*)frame, ld, fw, fh, tabs, rot, n, w, h, (float*)out, ldo); break;
+        default: hipLaunchKernelGGL((k_extent_gather_rot<FT, double>), grid, thr, 0, st, (const FT*)frame, ld, fw, fh, tabs, rot, n, w, h, (double*)out, ldo); break;
     }
 }
 
@@ -144,9 +266,9 @@ void hg_patcher_free(hg_patcher* p) {
     delete p;
 }
 
-int hg_patcher_extract_device(hg_patcher* p, const void* frame_dev, int frame_dtype, int frame_h, int frame_w, int64_t ld,
-                              const double* boxes_dev, int64_t n, int out_w, int out_h, void* out_dev, int out_dtype, int64_t ldo,
-                              void* stream) {
+int hg_patcher_extract_rotate_device(hg_patcher* p, const void* frame_dev, int frame_dtype, int frame_h, int frame_w, int64_t ld,
+                                     const double* boxes_dev, const double* delta_angs_dev, int64_t n, int out_w, int out_h, void* out_dev,
+                                     int out_dtype, int64_t ldo, void* stream) {
     return guarded([&] {
         check_args(p, frame_dev, frame_dtype, frame_h, frame_w, ld, boxes_dev, n, out_w, out_h, out_dev, out_dtype, ldo);
         if (n == 0) return;
@@ -157,16 +279,34 @@ int hg_patcher_extract_device(hg_patcher* p, const void* frame_dev, int frame_dt
         if ((n_ent + 255) / 256 > 0x7fffffffll) hg::fail(HG_ERR_ARG, "too many boxes");
         hipLaunchKernelGGL(k_extent_tables, (unsigned)((n_ent + 255) / 256), 256, 0, st, boxes_dev, n, out_w, out_h, frame_w, frame_h,
                            (int32_t*)p->tabs.p);
-        if (frame_dtype == HG_U8)
+        if (delta_angs_dev) {
+            if (frame_w >= 32768 || frame_h >= 32768) hg::fail(HG_ERR_ARG, "rotated windows need a frame smaller than 32768 pixels per side");
+            p->rot.alloc((size_t)n * sizeof(RotCoef));
+            hipLaunchKernelGGL(k_rot_coefs, (unsigned)((n + 255) / 256), 256, 0, st, boxes_dev, delta_angs_dev, n, frame_w, frame_h, (RotCoef*)p->rot.p);
+            if (frame_dtype == HG_U8)
+                launch_gather_rot<uint8_t>(frame_dev, ld, frame_w, frame_h, (const int32_t*)p->tabs.p, (const RotCoef*)p->rot.p, n, out_w, out_h, out_dev,
+                                           out_dtype, ldo, st);
+            else
+                launch_gather_rot<float>(frame_dev, ld, frame_w, frame_h, (const int32_t*)p->tabs.p, (const RotCoef*)p->rot.p, n, out_w, out_h, out_dev,
+                                         out_dtype, ldo, st);
+        } else if (frame_dtype == HG_U8) {
             launch_gather<uint8_t>(frame_dev, ld, (const int32_t*)p->tabs.p, n, out_w, out_h, out_dev, out_dtype, ldo, st);
-        else
+        } else {
             launch_gather<float>(frame_dev, ld, (const int32_t*)p->tabs.p, n, out_w, out_h, out_dev, out_dtype, ldo, st);
+        }
         HG_HIP(hipGetLastError());
     });
 }
 
-int hg_patcher_extract(hg_patcher* p, const void* frame, int frame_dtype, int frame_h, int frame_w, int64_t ld, const double* boxes,
-                       int64_t n, int out_w, int out_h, void* out, int out_dtype, int64_t ldo) {
+int hg_patcher_extract_device(hg_patcher* p, const void* frame_dev, int frame_dtype, int frame_h, int frame_w, int64_t ld,
+                              const double* boxes_dev, int64_t n, int out_w, int out_h, void* out_dev, int out_dtype, int64_t ldo,
+                              void* stream) {
+    return hg_patcher_extract_rotate_device(p, frame_dev, frame_dtype, frame_h, frame_w, ld, boxes_dev, nullptr, n, out_w, out_h, out_dev, out_dtype,
+                                            ldo, stream);
+}
+
+int hg_patcher_extract_rotate(hg_patcher* p, const void* frame, int frame_dtype, int frame_h, int frame_w, int64_t ld, const double* boxes,
+                              const double* delta_angs, int64_t n, int out_w, int out_h, void* out, int out_dtype, int64_t ldo) {
     return guarded([&] {
         check_args(p, frame, frame_dtype, frame_h, frame_w, ld, boxes, n, out_w, out_h, out, out_dtype, ldo);
         if (n == 0) return;
@@ -175,13 +315,20 @@ int hg_patcher_extract(hg_patcher* p, const void* frame, int frame_dtype, int fr
         p->frame.alloc((size_t)frame_h * frame_w * fs);
         HG_HIP(hipMemcpy2D(p->frame.p, (size_t)frame_w * fs, frame, (size_t)ld * fs, (size_t)frame_w * fs, (size_t)frame_h, hipMemcpyHostToDevice));
         p->boxes.upload(boxes, (size_t)n * 4 * 8);
+        if (delta_angs) p->angles.upload(delta_angs, (size_t)n * 8);
         const size_t row = (size_t)out_w * out_h;
         p->out.alloc((size_t)n * row * os);
-        int rc = hg_patcher_extract_device(p, p->frame.p, frame_dtype, frame_h, frame_w, frame_w, (const double*)p->boxes.p, n, out_w, out_h,
-                                           p->out.p, out_dtype, (int64_t)row, nullptr);
+        int rc = hg_patcher_extract_rotate_device(p, p->frame.p, frame_dtype, frame_h, frame_w, frame_w, (const double*)p->boxes.p,
+                                                  delta_angs ? (const double*)p->angles.p : nullptr, n, out_w, out_h, p->out.p, out_dtype,
+                                                  (int64_t)row, nullptr);
         if (rc != HG_OK) hg::fail(rc, "%s", hg_last_error());
         HG_HIP(hipMemcpy2D(out, (size_t)ldo * os, p->out.p, row * os, row * os, (size_t)n, hipMemcpyDeviceToHost));
     });
+}
+
+int hg_patcher_extract(hg_patcher* p, const void* frame, int frame_dtype, int frame_h, int frame_w, int64_t ld, const double* boxes,
+                       int64_t n, int out_w, int out_h, void* out, int out_dtype, int64_t ldo) {
+    return hg_patcher_extract_rotate(p, frame, frame_dtype, frame_h, frame_w, ld, boxes, nullptr, n, out_w, out_h, out, out_dtype, ldo);
 }
 
 }  // extern "C"

@@ -1,0 +1,59 @@
+"""Synthetic stand-in for the reference's detection pipeline (Pipelines/Pipeline_experimental.txt): the 17 face stages
+(FaceDetectUpdated.py:665 ``range(num_networks - 5)``) with the pipeline's structure — which stages own a network, which
+reuse the previous features (``None0``), classifier input widths 9 / 10 / 20 — but synthetic networks (the trained flows
+are stripped, .MISSING_LARGE_BLOBS) and synthetic Gaussian classifiers calibrated on the synthetic networks' features.
+It exists so that BASELINE.json configs[2] (one 1920x1080 frame through the whole pyramid and cascade) can be run and
+timed; it detects nothing meaningful.  Offline construction, not an execute path.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import grid
+from .cascade import Stage
+from .classifier import GaussianClassifier
+
+# (stage name, owns a network, classifier input width) — Pipelines/Pipeline_experimental.txt:5-55
+FACE_STAGES = [("Disc1", True, 9), ("PosX0", True, 10), ("PosY0", False, 10), ("PAng0", False, 20), ("Scale0", False, 20),
+               ("Disc3", True, 9), ("PosX1", True, 20), ("PosY1", False, 20), ("PAng1", False, 20), ("Scale1", False, 20),
+               ("Disc5", True, 9), ("PosX2", True, 20), ("PosY2", False, 20), ("PAng2", False, 20), ("Scale2", False, 20),
+               ("Disc7", True, 9), ("Disc9", True, 9)]
+
+
+def quantile_classifier(feats, d, labels, ridge=1e-3, device=0):
+    """K = len(labels) Gaussian classes along the quantiles of the first feature: class means from the sample, one pooled
+    covariance, priors = bin fractions, avg_labels = labels.  Parameters in the layout of the reference's classifier
+    pickles (means, inv_covs, _sqrt_def_covs, p, avg_labels — SURVEY.md §8f-2)."""
+    f = np.asarray(feats, dtype=np.float64)[:, :d]
+    k = len(labels)
+    order = np.argsort(f[:, 0], kind="stable")
+    bins = np.array_split(order, k)
+    means = np.stack([f[b].mean(axis=0) for b in bins])
+    resid = np.concatenate([f[b] - means[i] for i, b in enumerate(bins)])
+    cov = resid.T @ resid / max(len(resid) - k, 1) + ridge * np.eye(d) * max(np.trace(resid.T @ resid) / len(resid) / d, 1e-12)
+    inv = np.linalg.inv(cov)
+    sqrt_det = np.sqrt(np.linalg.det(cov))
+    p = np.array([len(b) for b in bins], dtype=np.float64) / len(f)
+    return GaussianClassifier(means, np.stack([inv] * k), np.full(k, sqrt_det), p, labels=np.arange(k),
+                              avg_labels=np.asarray(labels, dtype=np.float64), device=device)
+
+
+def build_face_cascade(flow, features, pipeline=None, keep_fraction=0.1, n_classes=10, device=0):
+    """Stages of the synthetic face cascade.  ``flow``: the Flow every network-owning stage runs (the reference uses four
+    trained flows of one architecture); ``features``: (m, >= 20) features of a sample of windows, used to calibrate the
+    classifiers so that the first Disc stage keeps about ``keep_fraction`` of the windows and the pose stages propose
+    small corrections inside their training ranges (Pipeline header: Dx 40, Dy 20, Dang 22.5, scale 0.694..0.981)."""
+    p = dict(grid.FACE_PIPELINE if pipeline is None else pipeline)
+    k = n_classes
+    n_face = max(1, int(round(k * keep_fraction)))
+    lab = {
+        "Disc": np.array([0.0] * n_face + [1.0] * (k - n_face)),
+        "PosX": np.linspace(-0.2 * p["net_Dx"], 0.2 * p["net_Dx"], k),
+        "PosY": np.linspace(-0.2 * p["net_Dy"], 0.2 * p["net_Dy"], k),
+        "PAng": np.linspace(-0.3 * p["net_Dang"], 0.3 * p["net_Dang"], k),
+        "Scale": np.linspace(0.78, 0.87, k),
+    }
+    stages = []
+    for name, own, d in FACE_STAGES:
+        stages.append(Stage(name, flow if own else None, quantile_classifier(features, d, lab[name[:-1]], device=device)))
+    return stages

@@ -1,0 +1,111 @@
+"""The detection cascade around the hot call (BASELINE.json configs[2]): cascade glue restated from the reference
+(CPU, known answers) and the device-resident chain against it (GPU)."""
+import numpy as np
+import pytest
+
+from oracle import cascade_restate as CR
+from pyfaceanalysis_amd import grid
+
+
+def test_glue_known_answers():
+    """update_current_subimage_coordinates / identify_patches_to_discard (face_analysis.py:803-887) on hand-computed cases."""
+    c = np.array([[10.0, 20.0, 73.0, 83.0], [100.0, 50.0, 227.0, 177.0]])
+    a = np.array([0.0, 3.0])
+    cx, _ = CR.update_coordinates("PosX", c.copy(), a.copy(), np.array([12.8, -6.4]), 128, 128)
+    assert np.allclose(cx[:, [0, 2]], [[10 - 12.8 * 63 / 128, 73 - 12.8 * 63 / 128], [100 + 6.4 * 127 / 128, 227 + 6.4 * 127 / 128]])
+    assert np.array_equal(cx[:, [1, 3]], c[:, [1, 3]])
+    _, an = CR.update_coordinates("PAng", c.copy(), a.copy(), np.array([5.0, -1.0]), 128, 128)
+    assert np.array_equal(an, [5.0, 2.0])
+    cs, _ = CR.update_coordinates("Scale", c.copy(), a.copy(), np.array([0.825, 0.4125]), 128, 128)
+    assert np.allclose(cs[0], c[0]) and np.allclose(cs[1], [163.5 - 127, 113.5 - 127, 163.5 + 127, 113.5 + 127])
+    cd, ad = CR.update_coordinates("Disc", c.copy(), a.copy(), np.array([0.1, 0.9]), 128, 128)
+    assert np.array_equal(cd, c) and np.array_equal(ad, a)
+    oi = np.array([0, 1])
+    lvl = np.array([[20.0, 10.0, 89.1], [40.0, 20.0, 179.6]])
+    w = CR.patches_to_discard("PosX", cx, a, None, oi, c, np.zeros(2), lvl, 0.694, 0.981, 22.5, 0.5)
+    assert list(w) == [False, False]
+    far = cx.copy()
+    far[0, [0, 2]] += 28.4                  # centre now 22.1 px from the original one: limit 20 * 1.1
+    assert list(CR.patches_to_discard("PosX", far, a, None, oi, c, np.zeros(2), lvl, 0.694, 0.981, 22.5, 0.5)) == [True, False]
+    assert list(CR.patches_to_discard("PAng", c, np.array([24.74, -24.76]), None, oi, c, np.zeros(2), lvl, 0.694, 0.981, 22.5, 0.5)) == [False, True]
+    assert list(CR.patches_to_discard("Disc", c, a, np.array([0.94, 0.95]), oi, c, np.zeros(2), lvl, 0.694, 0.981, 22.5, 0.95)) == [False, True]
+    big = c.copy()
+    big[1] = [0.0, 0.0, 300.0, 300.0]
+    assert list(CR.patches_to_discard("Scale", big, a, None, oi, c, np.zeros(2), lvl, 0.694, 0.981, 22.5, 0.5)) == [False, True]
+
+
+def test_stage_loop_on_cpu_callables():
+    """The stage loop (FaceDetectUpdated.py:665-766) with toy callables: extraction only where the reference extracts,
+    networks only where the pipeline has one, survivors compacted after every stage."""
+    names = ["Disc1", "PosX0", "PosY0", "Disc3", "Disc9"]
+    has_net = [True, True, False, True, True]
+    boxes = np.array([[i * 10.0, 0.0, i * 10.0 + 31, 31.0] for i in range(6)])
+    level = np.tile([10.0, 5.0, 45.25], (6, 1))
+    calls = {"extract": 0, "execute": []}
+
+    def extract(coords, dang):
+        calls["extract"] += 1
+        return coords[:, :1] * np.ones((1, 4))
+
+    def execute(k, subs):
+        calls["execute"].append((k, len(subs)))
+        return subs[:, :2] / 50.0
+
+    def regress(k, sl):
+        return sl[:, 0]                       # Disc1: cut-off 0.95 -> windows 0..4 stay (x0/50 < 0.95)
+    out = CR.run_cascade(names, has_net, boxes, level, grid.FACE_PIPELINE, extract, execute, regress)
+    # extraction: Disc1, Disc3 (previous is PosY); NOT PosX0 / Disc9 (previous is Disc), NOT PosY0 (no network)
+    assert calls["extract"] == 2 and [k for k, _ in calls["execute"]] == [0, 1, 3, 4]
+    assert out["counts"][0] == 5 and out["counts"][-1] <= out["counts"][0]
+    assert len(out["coords"]) == out["counts"][-1] == len(out["confidence"])
+
+
+@pytest.mark.gpu
+def test_device_cascade_matches_restated_loop(native_lib, nets):
+    """DeviceCascade (extract -> execute -> regression -> update -> discard -> compaction, all on the GPU) against the
+    restated stage loop driven by PIL windows and the SAME device features/regression (so only the glue is compared):
+    identical survivor sets, counts, coordinates and angles; then the features themselves against the oracle."""
+    import torch
+    from oracle import mdp_restate, pil_restate
+    from pyfaceanalysis_amd import synth_cascade
+    from pyfaceanalysis_amd.cascade import DeviceCascade, frame_windows
+    from pyfaceanalysis_amd.flow import Flow
+    from pyfaceanalysis_amd.patches import Patcher
+    nodes = nets("T5L-16")
+    flow = Flow(nodes, output_dtype=np.float32)
+    rng = np.random.default_rng(21)
+    frame = np.rint(rng.integers(0, 256, (90, 160)).astype(np.float64)).astype(np.uint8)
+    pipe = dict(grid.FACE_PIPELINE)
+    K = 10                                   # T5L-16 has 10 outputs: classifier widths capped to it
+    boxes, level = frame_windows(160, 90, 0.3, pipe, (16, 16))
+    pt = Patcher()
+    subs0 = pt.extract(frame, boxes, (16, 16), dtype=np.uint8)
+    feats = flow.execute(subs0)
+    stages = synth_cascade.build_face_cascade(flow, feats, pipe, keep_fraction=0.4)
+    for st in stages:                        # classifiers of width 20 do not fit this small net: rebuild at width <= 10
+        if st.classifier.input_dim > K:
+            st.classifier = synth_cascade.quantile_classifier(feats, K, st.classifier.avg_labels)
+    dc = DeviceCascade(stages, (16, 16), K, pipe)
+    got = dc.detect(torch.from_numpy(frame).cuda(), smallest_face=0.3)
+
+    def extract(coords, dang):
+        return pt.extract(frame, coords, (16, 16), dtype=np.uint8, delta_angs=dang) if len(coords) else np.zeros((0, 256), np.uint8)
+
+    def execute(k, subs):
+        return flow.execute(subs)
+
+    def regress(k, sl):
+        return stages[k].classifier.regression(np.ascontiguousarray(sl[:, :stages[k].classifier.input_dim]))
+    ref = CR.run_cascade([s.name for s in stages], [s.flow is not None for s in stages], boxes, level, pipe, extract, execute, regress)
+    assert got["counts"] == ref["counts"] and got["rows_executed"] == ref["rows_executed"], (got["counts"], ref["counts"])
+    assert 0 < got["counts"][-1] < len(boxes) and got["counts"][0] < len(boxes)
+    assert np.array_equal(got["orig_index"], ref["orig_index"])
+    assert np.array_equal(got["coords"], ref["coords"]) and np.array_equal(got["angles"], ref["angles"])
+    assert np.allclose(got["confidence"], ref["confidence"], rtol=1e-12, atol=1e-12)
+    assert np.abs(got["angles"]).max() > 0           # rotated extraction really took part
+    # the pieces the loop was fed: windows vs PIL's rule, features vs the oracle
+    assert np.array_equal(subs0[::7], pil_restate.extract_subimages_rotate(frame, boxes[::7], np.zeros(len(boxes[::7])), (16, 16)))
+    r = mdp_restate.execute_flow(nodes, subs0[::5])
+    assert np.abs(feats[::5] - r).max() <= 1e-4 * np.abs(r).max()
+    dc.close()
+    flow.close()

@@ -47,8 +47,53 @@ def test_patch_extraction_matches_pil(native_lib):
             assert got.dtype == dt and got.shape == (len(boxes), size[0] * size[1])
             assert np.array_equal(got.astype(np.int64), ref.astype(np.int64))
     assert p.extract(frame, np.zeros((0, 4)), (64, 64)).shape == (0, 4096)
-    with pytest.raises(NotImplementedError):
-        p.extract(frame, boxes[:2], (64, 64), angles=[0.0, 5.0])
+    p.close()
+
+
+def _pil_rotated_windows(frame, boxes, angs, size):
+    """The rule hg_extract.hip implements, evaluated by PIL itself: rotate about the box centre, then EXTENT."""
+    from PIL import Image
+    im = Image.fromarray(frame, "L")
+    out = []
+    for b, a in zip(boxes, angs):
+        src = im if a % 360.0 == 0.0 else im.rotate(a, Image.NEAREST, center=((b[0] + b[2]) / 2.0, (b[1] + b[3]) / 2.0))
+        out.append(np.asarray(src.transform(size, Image.EXTENT, tuple(b), Image.NEAREST)).reshape(-1))
+    return np.stack(out)
+
+
+@pytest.mark.gpu
+def test_rotated_patch_extraction_matches_pil(native_lib):
+    """Windows with delta_ang != 0 (every stage after the first PAng, face_analysis.py:781-783): bit-exact against
+    PIL's Image.rotate + Image.transform for the angle range of the cascade (|angle| <= net_Dang * 1.1 = 24.75 per
+    iteration, three iterations), right angles, multiples of 180 (PIL's scaling branch), tiny angles, boxes partly
+    outside the frame; and against the numpy restatement in oracle/pil_restate.py."""
+    from oracle import pil_restate
+    from pyfaceanalysis_amd.patches import Patcher
+    rng = np.random.default_rng(7)
+    frame = rng.integers(0, 256, (562, 1000), dtype=np.uint8)
+    boxes = np.concatenate([b for _, b in grid.frame_boxes(1000, 562, 0.2, subimage_size=(64, 64))])[::2]
+    extra = np.array([[-5.5, -3.25, 40.0, 30.0], [950.0, 520.0, 1020.5, 580.0], [10.0, 10.0, 11.0, 11.0], [300.0, 200.0, 363.0, 263.0]])
+    boxes = np.vstack([boxes, extra])
+    n = len(boxes)
+    angs = rng.uniform(-75.0, 75.0, n)
+    special = [0.0, 90.0, -90.0, 180.0, -180.0, 270.0, 360.0, 540.0, 1e-9, -1e-9, 22.5, -22.5, 45.0, 0.5]
+    angs[:len(special)] = special
+    angs[-4:] = [33.0, -12.0, 180.0, 181.0]
+    p = Patcher()
+    for size in ((64, 64), (37, 21)):
+        ref = _pil_rotated_windows(frame, boxes, angs, size)
+        got = p.extract(frame, boxes, size, dtype=np.uint8, delta_angs=angs)
+        bad = np.nonzero((got != ref).any(axis=1))[0]
+        assert bad.size == 0, (size, [(int(i), float(angs[i]), int((got[i] != ref[i]).sum())) for i in bad[:8]])
+    sub = slice(0, 40)
+    assert np.array_equal(pil_restate.extract_subimages_rotate(frame, boxes[sub], angs[sub], (64, 64)),
+                          p.extract(frame, boxes[sub], (64, 64), dtype=np.uint8, delta_angs=angs[sub]))
+    # float frames / float64 windows, and an all-zero angle vector equals the plain call
+    gf = p.extract(frame.astype(np.float32), boxes[:50], (64, 64), dtype=np.float64, delta_angs=angs[:50])
+    assert np.array_equal(gf, _pil_rotated_windows(frame, boxes[:50], angs[:50], (64, 64)).astype(np.float64))
+    assert np.array_equal(p.extract(frame, boxes, (64, 64), dtype=np.uint8, delta_angs=np.zeros(n)), p.extract(frame, boxes, (64, 64), dtype=np.uint8))
+    with pytest.raises(ValueError):
+        p.extract(frame, boxes[:2], (64, 64), delta_angs=[0.0])
     p.close()
 
 
