@@ -91,6 +91,70 @@ def cpu_baseline(nodes, n=256, reps=6):
     return out
 
 
+def frame_leg(flow, dev, reps=30):
+    """BASELINE.json configs[2] as an extra figure beside the headline: one synthetic 1920x1080 frame, smallest_face 0.1,
+    prescaled to 1000x562 (FaceDetectUpdated.py:551-556) -> 10 pyramid levels / 1738 first-stage windows of 128x128, all
+    levels as ONE batch, through the synthetic 17-stage face cascade (pyfaceanalysis_amd/synth_cascade.py: the pipeline's
+    stage structure, synthetic networks and classifiers), everything on the device: prescale, rotated window extraction,
+    flow.execute, Gaussian regression, coordinate update, discard, compaction; the host reads one survivor count per stage.
+    `first_stage_ms` is the chain extract -> execute -> regression over all 1738 windows with no host hop at all."""
+    import torch
+    from pyfaceanalysis_amd import grid, synth, synth_cascade
+    from pyfaceanalysis_amd.cascade import DeviceCascade, frame_windows
+    rng = np.random.default_rng(synth.INPUT_SEED)
+    frame = torch.from_numpy(np.rint(synth._box3(rng.integers(0, 256, (1080, 1920), dtype=np.uint8))).astype(np.uint8)).to(dev)
+    pipe = dict(grid.FACE_PIPELINE)
+    boot = DeviceCascade([synth_cascade.Stage("Disc1", flow, synth_cascade.quantile_classifier(rng.normal(size=(50, 20)), 9, [0.0, 1.0]))],
+                         (SIDE, SIDE), N_COLS, pipe)
+    small = boot.prescale(frame)
+    boxes, level = frame_windows(int(small.shape[1]), int(small.shape[0]), 0.1, pipe, (SIDE, SIDE))
+    n0 = len(boxes)
+    # calibration sample for the synthetic classifiers: first-stage features of this frame
+    b_dev = torch.from_numpy(boxes).to(dev)
+    subs = torch.empty((n0, SIDE * SIDE), dtype=torch.uint8, device=dev)
+    feats = torch.empty((n0, N_COLS), dtype=torch.float32, device=dev)
+    reg = torch.empty(n0, dtype=torch.float64, device=dev)
+    st = torch.cuda.current_stream(dev)
+    flow.reserve(n0)
+
+    def first_stage(clf):
+        boot.patcher.extract_device(small.data_ptr(), np.uint8, small.shape[0], small.shape[1], small.stride(0), b_dev.data_ptr(), n0,
+                                    (SIDE, SIDE), subs.data_ptr(), np.uint8, SIDE * SIDE, stream=st.cuda_stream)
+        flow.execute_device(subs.data_ptr(), np.uint8, n0, SIDE * SIDE, feats.data_ptr(), np.float32, N_COLS, N_COLS, stream=st.cuda_stream)
+        clf.regression_device(feats.data_ptr(), np.float32, n0, N_COLS, reg.data_ptr(), stream=st.cuda_stream)
+    first_stage(boot.stages[0].classifier)
+    torch.cuda.synchronize(dev)
+    stages = synth_cascade.build_face_cascade(flow, feats.cpu().numpy(), pipe, keep_fraction=0.1)
+    dc = DeviceCascade(stages, (SIDE, SIDE), N_COLS, pipe)
+    win = (boxes, level)
+    for _ in range(3):
+        out = dc.detect(dc.prescale(frame), smallest_face=0.1, windows=win)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = dc.detect(dc.prescale(frame), smallest_face=0.1, windows=win)
+    torch.cuda.synchronize(dev)
+    per_frame = (time.perf_counter() - t0) / reps
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(3):
+        first_stage(stages[0].classifier)
+    e0.record(st)
+    for _ in range(reps):
+        first_stage(stages[0].classifier)
+    e1.record(st)
+    torch.cuda.synchronize(dev)
+    res = {"frames_per_s": 1.0 / per_frame, "ms_per_frame": per_frame * 1e3, "frame": "1920x1080 synthetic, prescaled 1000x562, smallest_face 0.1",
+           "levels": int(len(np.unique(level[:, 2]))), "windows": n0, "stages": len(stages), "rows_executed": int(out["rows_executed"]),
+           "survivors_per_stage": [int(c) for c in out["counts"]], "detections": int(out["counts"][-1]),
+           "detections_per_s": float(out["counts"][-1]) / per_frame,
+           "first_stage_ms": e0.elapsed_time(e1) / reps,
+           "note": "synthetic networks and classifiers (trained flows are not shipped): timing only; host work per frame = "
+                   "grid constants + 17 launches' worth of ctypes calls + one 4-byte count readback per stage"}
+    dc.close()
+    boot.close()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -100,6 +164,7 @@ def main():
     ap.add_argument("--input-dtype", default="float32", choices=["float32", "uint8", "float64"])
     ap.add_argument("--generic", action="store_true", help="force the generic plan (diagnostic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-frame", action="store_true", help="skip the configs[2] frame leg (frames_per_s)")
     ap.add_argument("--node-kind", default="pca_exp_sfa", choices=["pca_exp_sfa", "igsfa"],
                     help="node type of the synthetic 11-layer net (default: the BASELINE.md workload)")
     args = ap.parse_args()
@@ -298,6 +363,10 @@ def main():
             "flops_per_subimage": flops_row, "padded_flops_per_subimage": int(info.padded_flops_per_row),
             "roofline": roof,
         }
+        if not args.no_frame and world == 1 and info.plan_kind == 1 and args.node_kind == "pca_exp_sfa":
+            fr = frame_leg(flow, dev)
+            out["frames_per_s"] = fr["frames_per_s"]
+            out["frame_leg"] = fr
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(nodes)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]

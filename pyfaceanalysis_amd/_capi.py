@@ -39,13 +39,18 @@ class NativeLibraryMissing(ImportError):
 def lib():
     """Load libhigsfa.so (built by ``python -m pyfaceanalysis_amd.build``).
 
-    Load order with PyTorch: import torch BEFORE the first call of this function when both are used in
-    one process.  The torch wheel bundles its own ROCm runtime (torch/lib/libamdhip64.so, librocblas.so,
-    librocsolver.so); loaded first, it is the one runtime everything binds to.  The other way round the
-    system runtime owns the GPU and torch then reports "No HIP GPUs are available"."""
+    Load order with PyTorch: the torch wheel bundles its own ROCm runtime (torch/lib/libamdhip64.so, librocblas.so,
+    librocsolver.so); loaded first, it is the one runtime everything binds to.  The other way round the system
+    runtime owns the GPU and a later ``import torch`` reports "No HIP GPUs are available".  So when torch is installed
+    it is imported here, before the library (HIGSFA_NO_TORCH=1 skips this for torch-free processes)."""
     global _lib
     if _lib is not None:
         return _lib
+    import sys
+    if "torch" not in sys.modules and not os.environ.get("HIGSFA_NO_TORCH"):
+        import importlib.util
+        if importlib.util.find_spec("torch") is not None:
+            import torch  # noqa: F401
     if not os.path.exists(_LIB_PATH):
         raise NativeLibraryMissing(
             "%s not found: the HIP library is the only execution path of this package; build it "

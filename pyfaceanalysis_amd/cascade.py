@@ -105,6 +105,21 @@ class DeviceCascade(object):
             if st.flow is not None:
                 st.flow.reserve(n0)
 
+    def prescale(self, frame, prescale_size=grid.PRESCALE_SIZE):
+        """FaceDetectUpdated.py:551-556: shrink so that the larger side is <= prescale_size, ``Image.resize(NEAREST)`` —
+        PIL's nearest resize is the EXTENT rule over the whole frame, so the patcher does it (bit-exact vs PIL in the tests)."""
+        t = self.torch
+        fh, fw = int(frame.shape[0]), int(frame.shape[1])
+        pw, ph = grid.prescaled_size(fw, fh, prescale_size)
+        if (pw, ph) == (fw, fh):
+            return frame
+        whole = t.tensor([[0.0, 0.0, float(fw), float(fh)]], dtype=t.float64, device=self.dev)
+        small = t.empty((ph, pw), dtype=t.uint8, device=self.dev)
+        self.patcher.extract_device(frame.data_ptr(), np.uint8, fh, fw, frame.stride(0), whole.data_ptr(), 1, (pw, ph), small.data_ptr(),
+                                    np.uint8, pw * ph, stream=t.cuda.current_stream(self.dev).cuda_stream)
+        self._keep = whole          # alive until the kernel has run
+        return small
+
     def detect(self, frame, smallest_face=0.2, windows=None):
         """frame: (H, W) uint8 torch tensor on this device.  Returns a dict of host arrays: coords (n, 4), angles (n),
         orig_index (n), confidence (n), counts (survivors after every stage), rows_executed."""

@@ -54,6 +54,8 @@ def build_face_cascade(flow, features, pipeline=None, keep_fraction=0.1, n_class
         "Scale": np.linspace(0.78, 0.87, k),
     }
     stages = []
+    width = np.asarray(features).shape[1]
     for name, own, d in FACE_STAGES:
+        d = min(d, width)                 # small test networks have fewer than 20 outputs
         stages.append(Stage(name, flow if own else None, quantile_classifier(features, d, lab[name[:-1]], device=device)))
     return stages
