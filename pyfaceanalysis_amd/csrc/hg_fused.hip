@@ -36,7 +36,25 @@ namespace hg {
 namespace {
 
 using namespace fused;
-constexpr int kStage0MaxCols = 1022;  // columns of one sub-image staged in LDS per chunk
+
+// Diagnostic switches (DESIGN.md "Diagnostic environment variables"), read ONCE when a plan is built — never on the
+// execute path.  None changes results beyond rounding.
+struct FusedOptions {
+    bool no_rem4 = false, ig_nofold = false, ig_resident = false, debug = false, no_prefetch_all = false;
+    int split = 1, stamp_stage = -1, ig_w = 0, ig_t = 0;
+    static FusedOptions from_env() {
+        FusedOptions o;
+        o.no_rem4 = getenv("HIGSFA_NO_REM4") != nullptr;
+        o.ig_nofold = getenv("HIGSFA_IG_NOFOLD") != nullptr;
+        o.ig_resident = getenv("HIGSFA_IG_RESIDENT") != nullptr;
+        o.debug = getenv("HIGSFA_DEBUG") != nullptr;
+        o.no_prefetch_all = getenv("HIGSFA_NO_PREFETCH_ALL") != nullptr;
+        if (const char* e = getenv("HIGSFA_SPLIT")) o.split = std::max(1, std::min(4, atoi(e)));
+        if (const char* e = getenv("HIGSFA_STAMP")) o.stamp_stage = atoi(e);
+        if (const char* e = getenv("HIGSFA_IG_SHAPE")) sscanf(e, "%d,%d", &o.ig_w, &o.ig_t);
+        return o;
+    }
+};
 
 // ---- host-side normal form ---------------------------------------------------------------------
 struct Aff {  // y = (x - a) W + b
@@ -139,9 +157,9 @@ bool to_chains(const TNode& n, std::vector<ChainT>& out, std::string& why) {
 // (their identity first affine would need more than kMaxMT tiles) but use the same folded map there: one GEMM
 // from the expanded input fragments to all output tiles instead of the G1 -> G2 -> G3 chain.
 // HIGSFA_IG_NOFOLD=1 keeps every iGSFA node on the three-GEMM form (tests).
-bool igsfa_affine(const FNode& fn, Aff& A2) {
+bool igsfa_affine(const FNode& fn, Aff& A2, bool nofold) {
     const int d = fn.in_dim, k = fn.ig_k, q = fn.ig_pca.out;
-    if (getenv("HIGSFA_IG_NOFOLD")) return false;
+    if (nofold) return false;
     int E = 0, id_off = -1;
     for (const ExpFunc& f : fn.funcs) {
         if (f.kind == E_IDENTITY && f.used(d) == d && id_off < 0) id_off = E;
@@ -191,10 +209,10 @@ bool igsfa_affine(const FNode& fn, Aff& A2) {
     return true;
 }
 
-void fold_igsfa(FNode& fn) {
+void fold_igsfa(FNode& fn, bool nofold) {
     const int d = fn.in_dim;
     Aff A2;
-    if (d > 16 * kMaxMT || !igsfa_affine(fn, A2)) return;
+    if (d > 16 * kMaxMT || !igsfa_affine(fn, A2, nofold)) return;
     Aff A1;
     A1.in = A1.out = d;
     A1.a = fn.ig_mean;
@@ -207,7 +225,7 @@ void fold_igsfa(FNode& fn) {
     fn.is_ig = false;
 }
 
-bool canon(const ChainT& c, int in_off, FNode& fn, std::string& why) {
+bool canon(const ChainT& c, int in_off, FNode& fn, std::string& why, const FusedOptions& opt) {
     fn.in_off = in_off;
     fn.in_dim = c.in_dim;
     fn.out_dim = c.out_dim;
@@ -236,7 +254,7 @@ bool canon(const ChainT& c, int in_off, FNode& fn, std::string& why) {
                 fn.funcs = {ExpFunc{E_IDENTITY, 0, 0, 1.0}};
             }
             fn.has_exp = true;
-            fold_igsfa(fn);
+            fold_igsfa(fn, opt.ig_nofold);
             return true;
         }
     int phase = 0;  // 0: before A1, 1: in A1, 2: after E, 3: in A2
@@ -264,7 +282,7 @@ bool canon(const ChainT& c, int in_off, FNode& fn, std::string& why) {
     return true;
 }
 
-bool build_stages(const TNode& root, std::vector<FStage>& stages, std::string& why) {
+bool build_stages(const TNode& root, std::vector<FStage>& stages, std::string& why, const FusedOptions& opt) {
     std::vector<int32_t> pending;  // composition of switchboards since the last layer group
     bool have_pending = false;
     std::vector<ChainT> group;
@@ -286,7 +304,7 @@ bool build_stages(const TNode& root, std::vector<FStage>& stages, std::string& w
         int off = 0;
         for (auto& c : group) {
             FNode fn;
-            if (!canon(c, off, fn, why)) return false;
+            if (!canon(c, off, fn, why, opt)) return false;
             off += c.in_dim;
             st.out_w += fn.out_dim;
             st.nodes.push_back(std::move(fn));
@@ -351,7 +369,11 @@ bool build_stages(const TNode& root, std::vector<FStage>& stages, std::string& w
 // coalesced load per K-block and tile, prefetched one K-block ahead.
 // REM: the last tile of both affines holds <= 4 real rows and its A fragments are stored in 4x4 form
 // (hg_fused_dev.hpp, "Remainder tiles").
-template <int MT1, int MT2, int T, bool STAMP = false, bool REM = false>
+// KBF > 0 (== P.kb1, checked at launch): all K-blocks of a node visit are fetched at once, one whole visit ahead — issued
+// before the second half of the previous node, whose MFMAs (no global loads of their own) cover the L2 / HBM round trip.
+// For small nodes (layer 2: four blocks of <= 4 k-steps) the one-block-ahead stream leaves each wave waiting ~1.5k cycles
+// per block (in-kernel stamps: GEMM 1 took 6x its MFMA time); costs KBF * T * 4 registers.
+template <int MT1, int MT2, int T, bool STAMP = false, bool REM = false, int KBF = 0>
 __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
     extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
     const int tid = threadIdx.x, nthr = blockDim.x;
@@ -412,6 +434,68 @@ __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
         if (tile[0] >= P.n_tiles) continue;
 #pragma unroll
         for (int t = 0; t < T; ++t) trow[t] = (uint32_t)(tile[t] < P.n_tiles ? tile[t] : tile[0]) * (uint32_t)P.nb_in;
+        if constexpr (KBF > 0) {
+            f32x4 bq[KBF][T];
+#pragma unroll
+            for (int kbi = 0; kbi < KBF; ++kbi) {
+                const int sb0 = __builtin_amdgcn_readfirstlane(stab[kbi].x);
+#pragma unroll
+                for (int t = 0; t < T; ++t) bq[kbi][t] = P.in[(size_t)(trow[t] + sb0) * 64 + lane];
+            }
+            for (int grp = part; grp < P.tile_groups; grp += P.tile_parts) {
+                const int tn0 = ((grp + P.tile_parts) * nw + wave) * T;
+                const bool has_next = grp + P.tile_parts < P.tile_groups && tn0 < P.n_tiles;
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const int tn = tn0 + t;
+                    trow_nx[t] = has_next ? (uint32_t)(tn < P.n_tiles ? tn : tn0) * (uint32_t)P.nb_in : trow[t];
+                }
+                for (int ln = 0; ln < gn; ++ln) {
+                    const f32x4* wA1 = smem + (size_t)ln * P.node_blocks * 64 + lane;
+                    const f32x4* wA2 = wA1 + KBF * MT1 * 64;
+                    const float* b1 = sb + ln * P.bias_floats;
+                    const int2* kt = stab + ln * KBF;
+                    f32x4 z[MT1][T];
+#pragma unroll
+                    for (int mt = 0; mt < MT1; ++mt) {
+                        f32x4 bb = *(const f32x4*)(b1 + mt * 16 + g * 4);
+#pragma unroll
+                        for (int t = 0; t < T; ++t) z[mt][t] = bb;
+                    }
+                    f32x4 d4[T];
+#pragma unroll
+                    for (int t = 0; t < T; ++t) d4[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kbi = 0; kbi < KBF; ++kbi) {
+                        const int nk = __builtin_amdgcn_readfirstlane(kt[kbi].y);
+                        if constexpr (REM) gemm_block_rem<MT1, T>(wA1 + kbi * MT1 * 64, bq[kbi], z, d4, nk);
+                        else gemm_block<MT1, T>(wA1 + kbi * MT1 * 64, bq[kbi], z, nk);
+                    }
+                    if constexpr (REM) {
+#pragma unroll
+                        for (int t = 0; t < T; ++t) z[MT1 - 1][t] += rem4_rows(d4[t], g);
+                    }
+                    {   // next visit's blocks: next node of this group on the same tiles, or the group's first node on the next tiles
+                        const bool in_group = ln + 1 < gn;
+                        const int2* ktn = in_group ? kt + KBF : stab;
+#pragma unroll
+                        for (int kbi = 0; kbi < KBF; ++kbi) {
+                            const int sbn = __builtin_amdgcn_readfirstlane(ktn[kbi].x);
+#pragma unroll
+                            for (int t = 0; t < T; ++t) bq[kbi][t] = P.in[(size_t)((in_group ? trow[t] : trow_nx[t]) + sbn) * 64 + lane];
+                        }
+                    }
+                    node_tail<MT1, MT2, T, REM>(P, wA2, b1 + MT1 * 16, (g0 + ln) * P.mto, z, tile, lane);
+                }
+                if (!has_next) break;
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    tile[t] = tn0 + t;
+                    trow[t] = trow_nx[t];
+                }
+            }
+            continue;
+        }
         f32x4 bf[T], bfn[T];
         int nk;
         {
@@ -626,7 +710,13 @@ StageFn pick_stage_m2(int mt2, int T) {
         default: return pick_stage_t<MT1, 4>(T);
     }
 }
-StageFn pick_stage(int mt1, int mt2, int T, bool rem = false) {
+StageFn pick_stage(int mt1, int mt2, int T, bool rem = false, int kbf = 0) {
+    if (kbf == 4 && T == 2) {     // whole-visit prefetch (small nodes of four K-blocks; plan time checks kb1 == 4)
+        if (rem && mt1 == 3 && mt2 == 3) return (StageFn)k_stage<3, 3, 2, false, true, 4>;
+        if (rem && mt1 == 2 && mt2 == 2) return (StageFn)k_stage<2, 2, 2, false, true, 4>;
+        if (!rem && mt1 == 3 && mt2 == 3) return (StageFn)k_stage<3, 3, 2, false, false, 4>;
+        if (!rem && mt1 == 2 && mt2 == 2) return (StageFn)k_stage<2, 2, 2, false, false, 4>;
+    }
     if (rem) {      // instantiated where the synthetic and test networks need it (plan time checks the same list)
         if (mt1 == 3 && mt2 == 3) return T == 2 ? (StageFn)k_stage<3, 3, 2, false, true> : (StageFn)k_stage<3, 3, 1, false, true>;
         if (mt1 == 2 && mt2 == 2) return T == 2 ? (StageFn)k_stage<2, 2, 2, false, true> : (StageFn)k_stage<2, 2, 1, false, true>;
@@ -675,7 +765,7 @@ struct HostStage {
 
 class FusedExecutor : public Executor {
 public:
-    FusedExecutor(const TNode& root, std::vector<FStage>&& fs) : in_dim_(root.in_dim), out_dim_(root.out_dim) {
+    FusedExecutor(const TNode& root, std::vector<FStage>&& fs, const FusedOptions& opt) : opt_(opt), out_dim_(root.out_dim) {
         std::vector<int32_t> prev_blk, prev_q;  // per column of the previous stage's output frame
         int prev_nb = 0;
         for (size_t si = 0; si < fs.size(); ++si) {
@@ -863,7 +953,7 @@ public:
             {
                 const int r1 = hs.p_max - 16 * (hs.mt1 - 1), r2 = hs.s_max - 16 * (hs.mt2 - 1);
                 hs.rem4 = si >= 2 && hs.has_exp && n > 4 && hs.mt1 == hs.mt2 && (hs.mt1 == 2 || hs.mt1 == 3) && r1 >= 1 && r1 <= 4 &&
-                          r2 >= 1 && r2 <= 4 && !getenv("HIGSFA_NO_REM4");
+                          r2 >= 1 && r2 <= 4 && !opt_.no_rem4;
                 if (hs.rem4) {
                     auto to4x4 = [](float* blk) {
                         float old[256];
@@ -959,8 +1049,7 @@ public:
         if (n > cap_rows_) reserve(n);
         // measured on MI355X at N = 4096: split 1 -> 0.656 ms, 2 -> 0.691, 3 -> 0.825, 4 -> 0.780: the
         // persistent kernels are sized to fill the chip, two of them only compete.  Off by default.
-        int split = 1;
-        if (const char* sp = getenv("HIGSFA_SPLIT")) split = std::max(1, std::min(4, atoi(sp)));
+        const int split = opt_.split;
         if (ev || n < 2048 || split == 1) {
             run_range(x, x_dtype, n, ldx, y, y_dtype, y_cols, ldy, st, ev, (f32x4*)bufA_.p, (f32x4*)bufB_.p);
             return;
@@ -1032,7 +1121,7 @@ public:
                 continue;
             }
             if (s.kind == 2 && s.ig_folded && s.n_nodes <= 8 && s.nf <= 2 && s.kb1 <= 8 && (int64_t)s.n_nodes * n_tiles <= 16384 &&
-                !getenv("HIGSFA_IG_RESIDENT")) {
+                !opt_.ig_resident) {
                 // top of an iGSFA hierarchy: one node and two tiles per small workgroup, output tiles split over waves
                 P.ig_folded = 1;
                 launch_igfold_split(P, s.mt2, n_tiles, st);
@@ -1052,8 +1141,7 @@ public:
                 int nwt = 1, T = 1;
                 {
                     static const int cand[][2] = {{12, 2}, {8, 2}, {4, 2}};
-                    int forced_w = 0, forced_t = 0;
-                    if (const char* e2 = getenv("HIGSFA_IG_SHAPE")) sscanf(e2, "%d,%d", &forced_w, &forced_t);   // experiments
+                    const int forced_w = opt_.ig_w, forced_t = opt_.ig_t;   // experiments (HIGSFA_IG_SHAPE)
                     for (auto& c : cand) {
                         if (forced_w && (c[0] != forced_w || c[1] != forced_t)) continue;
                         if (c[0] == 12 && (s.ig_folded || !(s.kb1 == 5 || s.kb1 == 6))) continue;   // k_igfold: <= 8 waves
@@ -1073,7 +1161,7 @@ public:
                     }
                 }
                 // folded layers stream their input blocks (k_igfold); HIGSFA_IG_RESIDENT=1 keeps them on k_igsfa
-                const bool igfold = s.ig_folded && !getenv("HIGSFA_IG_RESIDENT");
+                const bool igfold = s.ig_folded && !opt_.ig_resident;
                 StageFn fn = igfold ? pick_igfold(s.mt2, T) : pick_igsfa(s.mt1, s.mt2, T, s.kb1);
                 const int ig_occ = resident_blocks(fn, std::max(nwt, 4) * 64, ig_lds);
                 const int nw = std::max(nwt, 4);   // never fewer than 4 waves to copy a node's weights
@@ -1089,7 +1177,7 @@ public:
                 P.tile_parts = std::max(1, std::min(P.tile_groups, 256 * ig_occ / std::max(1, P.n_chunks)));
                 const size_t lds_bytes = ig_lds;
                 set_lds_limit(fn, lds_bytes);
-                if (getenv("HIGSFA_DEBUG")) fprintf(stderr, "[igsfa stage %d] nodes %d kb1 %d shape %dx%d occ %d lds %zu tile_groups %d parts %d\n", (int)si, s.n_nodes, s.kb1, nwt, T, ig_occ, lds_bytes, P.tile_groups, P.tile_parts);
+                if (opt_.debug) fprintf(stderr, "[igsfa stage %d] nodes %d kb1 %d shape %dx%d occ %d lds %zu tile_groups %d parts %d\n", (int)si, s.n_nodes, s.kb1, nwt, T, ig_occ, lds_bytes, P.tile_groups, P.tile_parts);
                 hipLaunchKernelGGL(fn, (unsigned)(P.n_chunks * P.tile_parts), nw * 64, lds_bytes, st, P);
                 std::swap(cur, nxt);
                 if (ev) HG_HIP(hipEventRecord(ev[e++], st));
@@ -1119,7 +1207,7 @@ public:
                     StageParams Q = base_params(stages_[1], nullptr, cur);
                     // second tiles of both layer-1 affines hold <= 4 real rows: 4x4x1 MFMA form (HIGSFA_NO_REM4: off)
                     const bool rem4 = stages_[1].p_max <= 20 && stages_[1].s_max <= 20 && stages_[1].nk2[1][0] <= 1 && stages_[1].nk2[1][1] <= 1 &&
-                                      !getenv("HIGSFA_NO_REM4");
+                                      !opt_.no_rem4;
                     StageFn2 fn = pick_stage01p(x_dtype, false, rem4);
                     const int thr01 = 64 * std::max(1, (s.max_chunk_nodes + 1) / 2);   // one wave per pair of layer-0 nodes
                     // two tiles of T = 2 batch tiles + 10 vectors of 16 floats (means, biases) per wave
@@ -1139,15 +1227,16 @@ public:
                         }
                     }
                     P.tile_parts = std::max(1, std::min(groups2, 256 * occ / std::max(1, P.n_chunks)));
-                    if (getenv("HIGSFA_DEBUG")) fprintf(stderr, "[front] occ %d threads %d lds %zu chunks %d tile_parts %d\n", occ, thr01, lds2, P.n_chunks, P.tile_parts);
-                    const char* stamp_env = getenv("HIGSFA_STAMP");
-                    if (stamp_env && atoi(stamp_env) == 0 && x_dtype == HG_F32) {
+                    if (opt_.debug) fprintf(stderr, "[front] occ %d threads %d lds %zu chunks %d tile_parts %d\n", occ, thr01, lds2, P.n_chunks, P.tile_parts);
+#ifdef HIGSFA_DIAG
+                    if (opt_.stamp_stage == 0 && x_dtype == HG_F32) {
                         fn = pick_stage01p(HG_F32, true, rem4);
                         stamp_blocks_ = P.n_chunks * P.tile_parts;
                         stamp_buf_.alloc((size_t)stamp_blocks_ * 8 * 8 * 8);
                         HG_HIP(hipMemsetAsync(stamp_buf_.p, 0, stamp_buf_.bytes, st));
                         P.stamps = (unsigned long long*)stamp_buf_.p;
                     }
+#endif
                     hipLaunchKernelGGL(fn, (unsigned)(P.n_chunks * P.tile_parts), thr01, lds2, st, P, Q);
                     if (P.stamps) {
                         HG_HIP(hipStreamSynchronize(st));
@@ -1221,7 +1310,8 @@ public:
                 // cost(P) = rounds of resident workgroups x (weight copy + tile iterations per workgroup)
                 const int64_t g8 = (int64_t)(n_groups + 7) / 8 * 8;
                 size_t lds_probe = (size_t)npg * s.node_blocks * 1024 + (size_t)npg * s.bias_floats * 4 + (size_t)npg * s.kb1 * 8;
-                const double capacity = 256.0 * resident_blocks(pick_stage(s.mt1, s.mt2, T, s.rem4), nw * 64, lds_probe);
+                const int kbf = (s.kb1 == 4 && T == 2 && s.mt1 == s.mt2 && (s.mt1 == 2 || s.mt1 == 3) && !opt_.no_prefetch_all) ? 4 : 0;
+                const double capacity = 256.0 * resident_blocks(pick_stage(s.mt1, s.mt2, T, s.rem4, kbf), nw * 64, lds_probe);
                 int tile_parts = 1;
                 double best = 1e300;
                 for (int pp = 1; pp <= tile_groups; ++pp) {
@@ -1240,9 +1330,9 @@ public:
                 const int64_t blocks = (int64_t)((P.n_chunks + 7) / 8) * 8 * tile_parts;
                 if (blocks > 0x7fffffffll) fail(HG_ERR_ARG, "batch too large");
                 size_t lds_bytes = (size_t)npg * s.node_blocks * 1024 + (size_t)npg * s.bias_floats * 4 + (size_t)npg * s.kb1 * 8;
-                StageFn fn = pick_stage(s.mt1, s.mt2, T, s.rem4);
-                const char* stamp_env = getenv("HIGSFA_STAMP");
-                if (stamp_env && atoi(stamp_env) == (int)si && s.mt1 == s.mt2 && (s.mt1 == 4 || s.mt1 == 3) && T == 2 && !s.rem4) {
+                StageFn fn = pick_stage(s.mt1, s.mt2, T, s.rem4, kbf);
+#ifdef HIGSFA_DIAG
+                if (opt_.stamp_stage == (int)si && s.mt1 == s.mt2 && (s.mt1 == 4 || s.mt1 == 3) && T == 2 && !s.rem4 && kbf == 0) {
                     // diagnostic instantiation with s_memtime stamps (never used in timed runs)
                     fn = s.mt1 == 4 ? (StageFn)k_stage<4, 4, 2, true> : (StageFn)k_stage<3, 3, 2, true>;
                     stamp_buf_.alloc((size_t)blocks * 8 * 6 * 8);
@@ -1250,6 +1340,7 @@ public:
                     P.stamps = (unsigned long long*)stamp_buf_.p;
                     stamp_blocks_ = (int)blocks;
                 }
+#endif
                 set_lds_limit(fn, lds_bytes);
                 hipLaunchKernelGGL(fn, (unsigned)blocks, nw * 64, lds_bytes, st, P);
                 if (P.stamps) {
@@ -1531,7 +1622,7 @@ private:
         // folded form (see igsfa_affine): one GEMM from the expanded input to all output tiles
         std::vector<Aff> folded_a2(n);
         bool folded = true;
-        for (int ni = 0; ni < n && folded; ++ni) folded = igsfa_affine(st.nodes[ni], folded_a2[ni]);
+        for (int ni = 0; ni < n && folded; ++ni) folded = igsfa_affine(st.nodes[ni], folded_a2[ni], opt_.ig_nofold);
         hs.ig_folded = folded;
         if (folded) hs.ig_has_lr = false;
         const int KB = hs.kb1, MO = (out_max + 15) / 16, MS = folded ? MO : (k_max + 15) / 16, nf = hs.nf;
@@ -1677,7 +1768,8 @@ private:
 
     int s0_pos(int r, int g) const { return s0_transpose_ ? 4 * g + r : 4 * r + g; }
 
-    int in_dim_, out_dim_;
+    FusedOptions opt_;
+    int out_dim_;
     bool s0_transpose_ = false, fuse01_ = false;
     std::vector<HostStage> stages_;
     std::vector<int32_t> col_base_;
@@ -1697,7 +1789,8 @@ private:
 std::unique_ptr<Executor> make_fused_executor(const TNode& root, std::string* why_not) {
     std::vector<FStage> stages;
     std::string why;
-    if (!build_stages(root, stages, why)) {
+    const FusedOptions opt = FusedOptions::from_env();
+    if (!build_stages(root, stages, why, opt)) {
         if (why_not) *why_not = why;
         return nullptr;
     }
@@ -1719,7 +1812,7 @@ std::unique_ptr<Executor> make_fused_executor(const TNode& root, std::string* wh
     }
     if (why_not) why_not->clear();
     try {
-        return std::make_unique<FusedExecutor>(root, std::move(stages));
+        return std::make_unique<FusedExecutor>(root, std::move(stages), opt);
     } catch (const Error& e) {      // a structure the fused kernels do not cover: generic plan instead
         if (why_not) *why_not = e.what();
         return nullptr;

@@ -536,11 +536,15 @@ StageFn pick_stage0p(int x_dtype) {
 }
 StageFn2 pick_stage01p(int x_dtype, bool stamp, bool rem4) {
     if (rem4) {
+#ifdef HIGSFA_DIAG
         if (stamp && x_dtype == HG_F32) return (StageFn2)k_stage01p<float, true, true>;
+#endif
         return x_dtype == HG_U8 ? (StageFn2)k_stage01p<uint8_t, false, true>
                                 : x_dtype == HG_F32 ? (StageFn2)k_stage01p<float, false, true> : (StageFn2)k_stage01p<double, false, true>;
     }
+#ifdef HIGSFA_DIAG
     if (stamp && x_dtype == HG_F32) return (StageFn2)k_stage01p<float, true>;
+#endif
     return x_dtype == HG_U8 ? (StageFn2)k_stage01p<uint8_t> : x_dtype == HG_F32 ? (StageFn2)k_stage01p<float> : (StageFn2)k_stage01p<double>;
 }
 

@@ -48,10 +48,12 @@ def build_face_cascade(flow, features, pipeline=None, keep_fraction=0.1, n_class
     n_face = max(1, int(round(k * keep_fraction)))
     lab = {
         "Disc": np.array([0.0] * n_face + [1.0] * (k - n_face)),
-        "PosX": np.linspace(-0.2 * p["net_Dx"], 0.2 * p["net_Dx"], k),
-        "PosY": np.linspace(-0.2 * p["net_Dy"], 0.2 * p["net_Dy"], k),
-        "PAng": np.linspace(-0.3 * p["net_Dang"], 0.3 * p["net_Dang"], k),
-        "Scale": np.linspace(0.78, 0.87, k),
+        # small corrections: the synthetic networks carry no face semantics, so a window that moved far would get unrelated
+        # features at the next Disc stage and the cascade would die out after two iterations instead of exercising all 17
+        "PosX": np.linspace(-0.03 * p["net_Dx"], 0.03 * p["net_Dx"], k),
+        "PosY": np.linspace(-0.03 * p["net_Dy"], 0.03 * p["net_Dy"], k),
+        "PAng": np.linspace(-0.1 * p["net_Dang"], 0.1 * p["net_Dang"], k),
+        "Scale": np.linspace(0.815, 0.835, k),
     }
     stages = []
     width = np.asarray(features).shape[1]
