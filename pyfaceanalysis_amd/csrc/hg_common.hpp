@@ -48,7 +48,9 @@ enum ExpKind : uint32_t { E_IDENTITY = 0, E_ABS_POW = 1, E_SIGNED_POW = 2, E_QUA
 struct ExpFunc {
     uint32_t kind, sel, k;
     double expo;
-    int used(int d) const { return sel > 0 && (int)sel < d ? (int)sel : d; }
+    // columns the function reads: the first `sel` (cuicuilco's sel_exp(n, f) slices x[:, :n], which numpy clamps), 0 = all.
+    // Compared unsigned: a huge sel clamps to d instead of turning negative.
+    int used(int d) const { return sel > 0 && sel < (uint32_t)d ? (int)sel : d; }
     int out_dim(int d) const {
         int u = used(d);
         if (kind <= E_SIGNED_POW) return u;

@@ -89,6 +89,9 @@ struct FNode {
     Aff A1, A2;
     bool has_exp = false;
     std::vector<ExpFunc> funcs;
+    bool has_prod = false;              // cross-column products in the expansion -> k_stage_prod
+    bool has_clip = false;              // CutoffNode between expansion and second affine
+    double clip_lo = 0, clip_hi = 0;
     // iGSFA node: x0 = x - mean; s = sfa(expand(x0)) (scale folded in);
     // r = x0 - lr(s); q = pca(r); y = [s, q]
     bool is_ig = false, ig_has_lr = false;
@@ -109,6 +112,8 @@ bool flatten_leafs(const TNode& n, LeafSeq& s, std::string& why) {
     switch (n.kind) {
         case K_AFFINE:
         case K_EXPANSION:
+        case K_HEAD:
+        case K_CUTOFF:
         case K_IGSFA: s.push_back(&n); return true;
         case K_IDENTITY: return true;
         case K_FLOWNODE:
@@ -258,16 +263,36 @@ bool canon(const ChainT& c, int in_off, FNode& fn, std::string& why, const Fused
             return true;
         }
     int phase = 0;  // 0: before A1, 1: in A1, 2: after E, 3: in A2
+    auto head = [](Aff& a, int keep) {        // HeadNode after an affine: keep its first `keep` outputs
+        Aff r;
+        r.in = a.in;
+        r.out = keep;
+        r.a = a.a;
+        r.W.resize((size_t)a.in * keep);
+        for (int i = 0; i < a.in; ++i)
+            for (int o = 0; o < keep; ++o) r.W[(size_t)i * keep + o] = a.W[(size_t)i * a.out + o];
+        r.b.assign(a.b.begin(), a.b.begin() + keep);
+        a = std::move(r);
+    };
     for (const TNode* l : c.seq) {
         if (l->kind == K_AFFINE) {
             if (phase == 0) { fn.A1 = aff_of(*l); phase = 1; }
             else if (phase == 1) fn.A1 = fold(fn.A1, aff_of(*l));
             else if (phase == 2) { fn.A2 = aff_of(*l); phase = 3; }
             else fn.A2 = fold(fn.A2, aff_of(*l));
+        } else if (l->kind == K_HEAD) {
+            if (phase == 1) head(fn.A1, (int)l->out_dim);
+            else if (phase == 3) head(fn.A2, (int)l->out_dim);
+            else { why = "HeadNode that does not follow an affine node"; return false; }
+        } else if (l->kind == K_CUTOFF) {
+            if (phase != 2 || fn.has_clip) { why = "CutoffNode anywhere but between the expansion and the second affine"; return false; }
+            fn.has_clip = true;
+            fn.clip_lo = l->lo;
+            fn.clip_hi = l->hi;
         } else {  // expansion
             if (phase != 1) { why = "node chain is not [affine][expansion][affine]"; return false; }
             for (const ExpFunc& f : l->funcs)
-                if (f.kind > E_SIGNED_POW) { why = "expansion with cross-column products (QT / pair products)"; return false; }
+                if (f.kind > E_SIGNED_POW) fn.has_prod = true;
             fn.funcs = l->funcs;
             fn.has_exp = true;
             phase = 2;
@@ -331,6 +356,7 @@ bool build_stages(const TNode& root, std::vector<FStage>& stages, std::string& w
             }
             continue;
         }
+        if (c.kind == K_IDENTITY) continue;      // mdp IdentityNode between layers: nothing to execute
         std::vector<ChainT> chains;
         if (!to_chains(c, chains, why)) return false;
         bool merged = false;
@@ -752,7 +778,12 @@ struct HostStage {
     std::vector<int32_t> piece_col, koff;
     std::vector<float> kmean;
     int lds_stride = 0, max_chunk_nodes = 0, max_chunk_pieces = 0;
-    int kind = 0;            // 0: affine-expansion-affine layer, 1: row-major -> fragment gather, 2: iGSFA layer
+    int kind = 0;            // 0: affine-expansion-affine layer, 1: row-major -> fragment gather, 2: iGSFA layer, 3: table-driven expansion
+    int neb = 0;             // kind 3: K-blocks of the expanded input
+    bool has_clip = false;
+    float clip_lo = 0, clip_hi = 0;
+    std::vector<int32_t> etab;
+    DevBuf d_etab;
     bool from_x = false;     // reads the caller's row-major matrix
     bool ig_has_lr = false, ig_folded = false;
     int ig_nks[kMaxMT] = {};  // k-steps of each slow-feature tile
@@ -774,6 +805,15 @@ public:
                 if (stages_.empty()) add_gather0(st, prev_blk, prev_q, prev_nb);
                 build_ig_stage(st, prev_blk, prev_q, prev_nb);
                 continue;
+            }
+            {
+                bool table_driven = st.nodes[0].has_clip;
+                for (auto& nd : st.nodes) table_driven = table_driven || nd.has_prod;
+                if (table_driven) {
+                    if (stages_.empty()) add_gather0(st, prev_blk, prev_q, prev_nb);
+                    build_prod_stage(st, prev_blk, prev_q, prev_nb, (int)si);
+                    continue;
+                }
             }
             if (si > 0 && stages_.empty()) fail(HG_ERR_FORMAT, "internal: stage order");
             stages_.emplace_back();
@@ -1020,6 +1060,7 @@ public:
             s.d_bias.upload(s.bias.data(), s.bias.size() * 4);
             if (!s.kb1tab.empty()) s.d_kb1tab.upload(s.kb1tab.data(), s.kb1tab.size() * 4);
             if (!s.gcol.empty()) s.d_gcol.upload(s.gcol.data(), s.gcol.size() * 4);
+            if (!s.etab.empty()) s.d_etab.upload(s.etab.data(), s.etab.size() * 4);
             if (!s.chunks.empty()) {
                 s.d_chunks.upload(s.chunks.data(), s.chunks.size() * sizeof(DChunk));
                 s.d_runs.upload(s.runs.data(), s.runs.size() * sizeof(DRun));
@@ -1273,7 +1314,7 @@ public:
                     hipLaunchKernelGGL(fn, (unsigned)blocks, T == 4 ? 512 : 256, lds_bytes, st, P);
                 }
             } else {
-                if (s.n_nodes <= 4 && s.mt1 * s.nf <= 8 && (int64_t)s.n_nodes * n_tiles <= 8192) {
+                if (s.kind == 0 && s.n_nodes <= 4 && s.mt1 * s.nf <= 8 && (int64_t)s.n_nodes * n_tiles <= 8192) {
                     // top of the hierarchy: split the m-tiles of a node over the waves of a small workgroup
                     const int T = n_tiles >= 2 * 256 / std::max(1, s.n_nodes) ? 2 : 1;
                     const int groups = (n_tiles + T - 1) / T;
@@ -1283,6 +1324,12 @@ public:
                         hipLaunchKernelGGL(k_stage_splitm<2>, (unsigned)(groups * s.n_nodes), nwv * 64, lds_bytes, st, P, s.mt1, s.mt2);
                     else
                         hipLaunchKernelGGL(k_stage_splitm<1>, (unsigned)(groups * s.n_nodes), nwv * 64, lds_bytes, st, P, s.mt1, s.mt2);
+                    std::swap(cur, nxt);
+                    if (ev) HG_HIP(hipEventRecord(ev[e++], st));
+                    continue;
+                }
+                if (s.kind == 3) {
+                    launch_prod(s, P, n_tiles, st);
                     std::swap(cur, nxt);
                     if (ev) HG_HIP(hipEventRecord(ev[e++], st));
                     continue;
@@ -1384,7 +1431,7 @@ public:
         d_col_base_.free();
         for (auto& s : stages_) {
             s.d_afrag.free(); s.d_bias.free(); s.d_kb1tab.free(); s.d_chunks.free();
-            s.d_runs.free(); s.d_piece.free(); s.d_koff.free(); s.d_kmean.free(); s.d_gcol.free();
+            s.d_runs.free(); s.d_piece.free(); s.d_koff.free(); s.d_kmean.free(); s.d_gcol.free(); s.d_etab.free();
         }
         cap_rows_ = 0;
     }
@@ -1747,6 +1794,264 @@ private:
         hs.name = os.str();
     }
 
+    // Layer whose expansion holds cross-column products or is followed by a CutoffNode (k_stage_prod).  GEMM 1 as in any
+    // stage > 0; the expanded input is described column by column for the WIDEST node of the layer, 16 columns per K-block
+    // of GEMM 2; a narrower node's weights are scattered into that column order (columns it lacks get zero rows).
+    void build_prod_stage(FStage& st, std::vector<int32_t>& prev_blk, std::vector<int32_t>& prev_q, int& prev_nb, int si) {
+        stages_.emplace_back();
+        HostStage& hs = stages_.back();
+        hs.kind = 3;
+        hs.has_exp = true;
+        const int n = (int)st.nodes.size();
+        hs.n_nodes = n;
+        const std::vector<ExpFunc> all = st.nodes[0].funcs;
+        const int nf_all = (int)all.size();
+        std::vector<int> elem_of(nf_all, -1);          // function -> index among the element-wise ones
+        for (int fi = 0; fi < nf_all; ++fi)
+            if (all[fi].kind <= E_SIGNED_POW) {
+                elem_of[fi] = (int)hs.funcs.size();
+                hs.funcs.push_back(all[fi]);
+            }
+        hs.nf = (int)hs.funcs.size();
+        if (hs.nf > kMaxFuncs) fail(HG_ERR_FORMAT, "fused: more than 4 element-wise expansion functions");
+        hs.has_clip = st.nodes[0].has_clip;
+        hs.clip_lo = (float)st.nodes[0].clip_lo;
+        hs.clip_hi = (float)st.nodes[0].clip_hi;
+        hs.nb_in = prev_nb;
+        for (auto& nd : st.nodes) {
+            if (!nd.has_exp) fail(HG_ERR_FORMAT, "fused: linear node in a layer with product expansions");
+            hs.p_max = std::max(hs.p_max, nd.A1.out);
+            hs.s_max = std::max(hs.s_max, nd.A2.out);
+        }
+        hs.mt1 = (hs.p_max + 15) / 16;
+        hs.mt2 = (hs.s_max + 15) / 16;
+        hs.mto = hs.mt2;
+        for (int mt1 = 0; mt1 < hs.mt1; ++mt1)
+            for (int fi = 0; fi < hs.nf; ++fi) {
+                const int valid = std::max(0, std::min(16, hs.funcs[fi].used(hs.p_max) - 16 * mt1));
+                hs.nk2[mt1][fi] = (uint8_t)((valid + 3) / 4);
+            }
+        // product columns of a node of width p: (function, i, k) in the order GeneralExpansionNode stacks them
+        struct Col { int fi, i, k; };
+        auto products = [&](int p) {
+            std::vector<Col> cols;
+            for (int fi = 0; fi < nf_all; ++fi) {
+                const ExpFunc& f = all[fi];
+                const int u = f.used(p);
+                if (f.kind == E_QUADRATIC) { for (int i = 0; i < u; ++i) for (int k = i; k < u; ++k) cols.push_back({fi, i, k}); }
+                else if (f.kind == E_PAIR_ADJ) for (int i = 0; i + (int)f.k < u; ++i) cols.push_back({fi, i, i + (int)f.k});
+            }
+            return cols;
+        };
+        const std::vector<Col> cmax = products(hs.p_max);
+        const int E = (int)cmax.size();
+        hs.neb = (E + 15) / 16;
+        hs.nk_last = hs.neb ? (std::min(16, E - 16 * (hs.neb - 1)) + 3) / 4 : 0;
+        hs.etab.assign((size_t)std::max(hs.neb, 1) * 32, 0);
+        for (int c = 0; c < E; ++c) {
+            hs.etab[2 * c] = (int32_t)(0x80000000u | (uint32_t)(cmax[c].i * 64));     // byte offset of feature i in [feature][16 sub-images]
+            hs.etab[2 * c + 1] = cmax[c].k * 64;
+        }
+        // K-blocks of GEMM 1
+        struct NodeK {
+            std::vector<int> src, nk;
+            std::vector<std::vector<int>> kpos;
+        };
+        std::vector<NodeK> nks(n);
+        for (int ni = 0; ni < n; ++ni) {
+            FNode& nd = st.nodes[ni];
+            NodeK& K = nks[ni];
+            std::map<int, int> blk_index;
+            for (int c = 0; c < nd.in_dim; ++c) {
+                const int pc = st.conn[nd.in_off + c], blk = prev_blk[pc], q = prev_q[pc];
+                auto it = blk_index.find(blk);
+                int kb;
+                if (it == blk_index.end()) {
+                    kb = (int)K.src.size();
+                    blk_index[blk] = kb;
+                    K.src.push_back(blk);
+                    K.nk.push_back(0);
+                    for (int qq = 0; qq < 16; ++qq) K.kpos.emplace_back();
+                } else {
+                    kb = it->second;
+                }
+                K.kpos[kb * 16 + q].push_back(c);
+                K.nk[kb] = std::max(K.nk[kb], q / 4 + 1);
+            }
+            hs.kb1 = std::max(hs.kb1, (int)K.src.size());
+        }
+        hs.node_blocks = hs.kb1 * hs.mt1 + (hs.mt1 * hs.nf + hs.neb) * hs.mt2;
+        hs.bias_floats = (hs.mt1 + hs.mt2) * 16;
+        if ((size_t)hs.node_blocks * 1024 + (size_t)hs.bias_floats * 4 + (size_t)hs.kb1 * 8 + (size_t)hs.neb * 128 + (size_t)4 * hs.mt1 * 1024 > 150 * 1024)
+            fail(HG_ERR_FORMAT, "fused: one node needs %d KiB of weight fragments (%d product columns), more than a workgroup's LDS", hs.node_blocks, E);
+        hs.afrag.assign((size_t)n * hs.node_blocks * 256, 0.f);
+        hs.bias.assign((size_t)n * hs.bias_floats, 0.f);
+        hs.kb1tab.assign((size_t)n * hs.kb1 * 2, 0);
+        std::vector<int32_t> cur_blk, cur_q;
+        for (int ni = 0; ni < n; ++ni) {
+            FNode& nd = st.nodes[ni];
+            NodeK& K = nks[ni];
+            const int p = nd.A1.out, sdim = nd.A2.out;
+            float* wnode = hs.afrag.data() + (size_t)ni * hs.node_blocks * 256;
+            float* bnode = hs.bias.data() + (size_t)ni * hs.bias_floats;
+            std::vector<double> bias1 = nd.A1.b;
+            for (int c = 0; c < nd.in_dim; ++c)
+                for (int o = 0; o < p; ++o) bias1[o] -= nd.A1.a[c] * nd.A1.W[(size_t)c * p + o];
+            for (int kb = 0; kb < hs.kb1; ++kb) {
+                const bool real = kb < (int)K.src.size();
+                hs.kb1tab[((size_t)ni * hs.kb1 + kb) * 2] = real ? K.src[kb] : K.src[0];
+                hs.kb1tab[((size_t)ni * hs.kb1 + kb) * 2 + 1] = real ? K.nk[kb] : 0;
+                if (!real) continue;
+                hs.mfma_per_tile += (int64_t)K.nk[kb] * hs.mt1;
+                for (int mt = 0; mt < hs.mt1; ++mt) {
+                    float* blk = wnode + ((size_t)kb * hs.mt1 + mt) * 256;
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int i = lane & 15, gg = lane >> 4, fo = 16 * mt + q_of_row(i);
+                        if (fo >= p) continue;
+                        for (int r = 0; r < 4; ++r) {
+                            double w = 0;
+                            for (int c : K.kpos[kb * 16 + 4 * r + gg]) w += nd.A1.W[(size_t)c * p + fo];
+                            blk[lane * 4 + r] = (float)w;
+                        }
+                    }
+                }
+            }
+            for (int mt = 0; mt < hs.mt1; ++mt)
+                for (int gg = 0; gg < 4; ++gg)
+                    for (int r = 0; r < 4; ++r) {
+                        const int fo = 16 * mt + 4 * r + gg;
+                        bnode[mt * 16 + gg * 4 + r] = fo < p ? (float)bias1[fo] : 0.f;
+                    }
+            // rows of this node's W2: its own expanded columns in GeneralExpansionNode order
+            std::vector<int> foff(nf_all);
+            int eo = 0;
+            for (int fi = 0; fi < nf_all; ++fi) {
+                foff[fi] = eo;
+                eo += all[fi].out_dim(p);
+            }
+            if (eo != nd.A2.in) fail(HG_ERR_DIM, "fused: expansion width %d != second affine input_dim %d", eo, nd.A2.in);
+            std::map<std::tuple<int, int, int>, int> row_of;      // product (function, i, k) -> row
+            {
+                const std::vector<Col> cn = products(p);
+                std::vector<int> cnt(nf_all, 0);
+                for (auto& c : cn) row_of[std::make_tuple(c.fi, c.i, c.k)] = foff[c.fi] + cnt[c.fi]++;
+            }
+            std::vector<double> bias2 = nd.A2.b;
+            for (int c = 0; c < nd.A2.in; ++c)
+                for (int o = 0; o < sdim; ++o) bias2[o] -= nd.A2.a[c] * nd.A2.W[(size_t)c * sdim + o];
+            float* w2 = wnode + (size_t)hs.kb1 * hs.mt1 * 256;
+            for (int mt1 = 0; mt1 < hs.mt1; ++mt1)
+                for (int fa = 0; fa < nf_all; ++fa) {
+                    const int fi = elem_of[fa];
+                    if (fi < 0) continue;
+                    const int used = all[fa].used(p);
+                    hs.mfma_per_tile += (int64_t)hs.nk2[mt1][fi] * hs.mt2;
+                    for (int mt2 = 0; mt2 < hs.mt2; ++mt2) {
+                        float* blk = w2 + ((size_t)(mt1 * hs.nf + fi) * hs.mt2 + mt2) * 256;
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int i = lane & 15, gg = lane >> 4, fo = 16 * mt2 + q_of_row(i);
+                            if (fo >= sdim) continue;
+                            for (int r = 0; r < 4; ++r) {
+                                const int fz = 16 * mt1 + 4 * r + gg;
+                                if (fz >= used) continue;
+                                blk[lane * 4 + r] = (float)nd.A2.W[(size_t)(foff[fa] + fz) * sdim + fo];
+                            }
+                        }
+                    }
+                }
+            float* wp = w2 + (size_t)hs.mt1 * hs.nf * hs.mt2 * 256;
+            for (int eb = 0; eb < hs.neb; ++eb) {
+                hs.mfma_per_tile += (int64_t)(eb + 1 < hs.neb ? 4 : hs.nk_last) * hs.mt2;
+                for (int mt2 = 0; mt2 < hs.mt2; ++mt2) {
+                    float* blk = wp + ((size_t)eb * hs.mt2 + mt2) * 256;
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int i = lane & 15, gg = lane >> 4, fo = 16 * mt2 + q_of_row(i);
+                        if (fo >= sdim) continue;
+                        for (int r = 0; r < 4; ++r) {
+                            const int c = 16 * eb + 4 * r + gg;
+                            if (c >= E) continue;
+                            auto it = row_of.find(std::make_tuple(cmax[c].fi, cmax[c].i, cmax[c].k));
+                            if (it == row_of.end()) continue;        // a column only wider nodes have
+                            blk[lane * 4 + r] = (float)nd.A2.W[(size_t)it->second * sdim + fo];
+                        }
+                    }
+                }
+            }
+            for (int mt = 0; mt < hs.mt2; ++mt)
+                for (int gg = 0; gg < 4; ++gg)
+                    for (int r = 0; r < 4; ++r) {
+                        const int fo = 16 * mt + 4 * r + gg;
+                        bnode[hs.mt1 * 16 + mt * 16 + gg * 4 + r] = fo < sdim ? (float)bias2[fo] : 0.f;
+                    }
+            for (int f = 0; f < sdim; ++f) {
+                cur_blk.push_back(ni * hs.mto + f / 16);
+                cur_q.push_back(f % 16);
+            }
+        }
+        hs.nb_out = n * hs.mto;
+        prev_blk.swap(cur_blk);
+        prev_q.swap(cur_q);
+        prev_nb = hs.nb_out;
+        max_nb_ = std::max(max_nb_, hs.nb_out);
+        padded_flops_ += hs.mfma_per_tile * 2048 / 16;
+        std::ostringstream os;
+        os << "fused stage " << si << " (table-driven expansion: products" << (hs.has_clip ? ", clip" : "") << "): " << n << " nodes, K-blocks " << hs.kb1
+           << ", tiles " << hs.mt1 << "x" << hs.mt2 << ", " << hs.nf << " element-wise functions, " << E << " product columns in " << hs.neb
+           << " K-blocks, " << hs.mfma_per_tile << " MFMA/tile, " << hs.afrag.size() * 4 / 1024 << " KiB weights";
+        hs.name = os.str();
+    }
+
+    void launch_prod(HostStage& s, StageParams& P, int n_tiles, hipStream_t st) {
+        // per-wave z image: T * mt1 KiB; the node group takes what is left of ~52 KiB (three workgroups per CU: the product
+        // columns are LDS reads and multiplies between short MFMA runs, which only other waves can cover), more if one node needs it
+        static const int shapes[][2] = {{8, 2}, {4, 2}, {4, 1}};
+        int nw = 4, T = 1;
+        for (auto& sh : shapes) {
+            const int64_t tg = (n_tiles + sh[0] * sh[1] - 1) / (sh[0] * sh[1]);
+            if (sh[0] * sh[1] <= n_tiles && tg * s.n_nodes >= 256) {
+                nw = sh[0];
+                T = sh[1];
+                break;
+            }
+        }
+        while (nw * T > std::max(n_tiles, 1) && nw > 1) nw >>= 1;
+        const size_t zs_bytes = (size_t)nw * T * s.mt1 * 1024, et_bytes = (size_t)s.neb * 128;
+        const size_t per_node = (size_t)s.node_blocks * 1024 + (size_t)s.bias_floats * 4 + (size_t)s.kb1 * 8;
+        const size_t fixed = zs_bytes + et_bytes;
+        const int npg = (int)std::max<size_t>(1, std::min<size_t>(s.n_nodes, fixed + per_node <= 52 * 1024 ? (52 * 1024 - fixed) / per_node : 1));
+        const int n_groups = (s.n_nodes + npg - 1) / npg;
+        const int tile_groups = (n_tiles + nw * T - 1) / (nw * T);
+        const size_t lds_bytes = (size_t)npg * per_node + et_bytes + zs_bytes;
+        StageFn fn = pick_prod(s.mt1, s.mt2, T);
+        const double capacity = 256.0 * resident_blocks(fn, nw * 64, lds_bytes);
+        const int64_t g8 = (int64_t)(n_groups + 7) / 8 * 8;
+        int tile_parts = 1;
+        double best = 1e300;
+        for (int pp = 1; pp <= tile_groups; ++pp) {
+            const double rounds = std::ceil(g8 * pp / capacity);
+            const double cost = rounds * (0.35 + (double)((tile_groups + pp - 1) / pp));
+            if (cost < best - 1e-9) {
+                best = cost;
+                tile_parts = pp;
+            }
+        }
+        P.nodes_per_group = npg;
+        P.nodes_per_wg = npg;
+        P.n_chunks = n_groups;
+        P.tile_groups = tile_groups;
+        P.tile_parts = tile_parts;
+        P.etab = (const int2*)s.d_etab.p;
+        P.neb = s.neb;
+        P.nk_last = s.nk_last;
+        P.has_clip = s.has_clip ? 1 : 0;
+        P.clip_lo = s.clip_lo;
+        P.clip_hi = s.clip_hi;
+        const int64_t blocks = (int64_t)((n_groups + 7) / 8) * 8 * tile_parts;
+        if (blocks > 0x7fffffffll) fail(HG_ERR_ARG, "batch too large");
+        set_lds_limit(fn, lds_bytes);
+        hipLaunchKernelGGL(fn, (unsigned)blocks, nw * 64, lds_bytes, st, P);
+    }
+
     // Layers 0 and 1 can share one kernel when a wave's two layer-0 node slots are exactly the two
     // children of one layer-1 node (see k_stage01p).
     bool can_fuse01() const {
@@ -1796,14 +2101,18 @@ std::unique_ptr<Executor> make_fused_executor(const TNode& root, std::string* wh
     }
     for (auto& st : stages) {
         const FNode& f0 = st.nodes[0];
-        if (f0.funcs.size() > (size_t)kMaxFuncs) {
+        bool table_driven = f0.has_clip;
+        for (auto& n : st.nodes) table_driven = table_driven || n.has_prod;
+        if (f0.funcs.size() > (size_t)kMaxFuncs && !table_driven) {
             if (why_not) *why_not = "more than 4 expansion functions";
             return nullptr;
         }
         for (auto& n : st.nodes) {
-            bool same = n.has_exp == f0.has_exp && n.is_ig == f0.is_ig && n.funcs.size() == f0.funcs.size();
+            bool same = n.has_exp == f0.has_exp && n.is_ig == f0.is_ig && n.funcs.size() == f0.funcs.size() && n.has_clip == f0.has_clip &&
+                        (!n.has_clip || (n.clip_lo == f0.clip_lo && n.clip_hi == f0.clip_hi));
             for (size_t i = 0; same && i < n.funcs.size(); ++i)
-                same = n.funcs[i].kind == f0.funcs[i].kind && n.funcs[i].expo == f0.funcs[i].expo && n.funcs[i].sel == f0.funcs[i].sel;
+                same = n.funcs[i].kind == f0.funcs[i].kind && n.funcs[i].expo == f0.funcs[i].expo && n.funcs[i].sel == f0.funcs[i].sel &&
+                       n.funcs[i].k == f0.funcs[i].k;
             if (!same) {
                 if (why_not) *why_not = "nodes of one layer use different expansions";
                 return nullptr;

@@ -53,6 +53,10 @@ struct StageParams {
     int32_t lds_stride, nk_last, vec4, contig4;
     int32_t ig_has_lr, ig_folded;   // k_igsfa: residual GEMM present; folded form (first GEMM covers all output tiles, no others)
     unsigned long long* stamps;   // diagnostic build only (HIGSFA_STAMP): per-wave cycle stamps
+    // k_stage_prod (hg_fused_prod.hip): table-driven expansion (products, clip)
+    const int2* etab;             // [neb][16] {kind << 16 | k << 8 | i, exponent bits}
+    int32_t neb, has_clip;
+    float clip_lo, clip_hi;
 };
 
 __device__ __forceinline__ unsigned long long stamp_now() {
@@ -218,6 +222,7 @@ StageFn pick_stage0p(int x_dtype);
 StageFn2 pick_stage01p(int x_dtype, bool stamp, bool rem4);
 StageFn pick_igsfa(int ms, int mo, int T, int kb1);                   // hg_fused_igsfa.hip
 StageFn pick_igfold(int mo, int T);
+StageFn pick_prod(int mt1, int mt2, int T);                           // hg_fused_prod.hip
 void launch_igfold_split(const StageParams& P, int mo, int n_tiles, hipStream_t st);                                                          // hg_fused_igsfa.hip
 void launch_im2frag(const void* x, int x_dtype, int64_t ldx, int64_t n_rows, int n_tiles, int nb, const int32_t* gcol, f32x4* out,
                     int vec4, hipStream_t st);

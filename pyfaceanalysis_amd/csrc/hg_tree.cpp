@@ -181,9 +181,9 @@ std::unique_ptr<TNode> read_node(Reader& r) {
                 f.k = r.u32(p + 8);
                 memcpy(&f.expo, p + 16, 8);
                 if (f.kind > E_PAIR_ADJ) fail(HG_ERR_FORMAT, "expansion: unknown function kind %u", f.kind);
-                // sel = number of leading columns the function reads (0 = all); k = pair distance
-                if (f.sel > n->in_dim) fail(HG_ERR_FORMAT, "expansion: function %u selects %u of %u columns", i, f.sel, n->in_dim);
-                const uint64_t u = f.sel ? f.sel : n->in_dim;
+                // sel = number of leading columns the function reads (0 = all; more than there are = all, as numpy slicing
+                // clamps); k = pair distance
+                const uint64_t u = (f.sel && f.sel < n->in_dim) ? f.sel : n->in_dim;
                 if ((f.kind == E_ABS_POW || f.kind == E_SIGNED_POW) && !(std::isfinite(f.expo) && f.expo > 0.0))
                     fail(HG_ERR_FORMAT, "expansion: function %u has exponent %g (must be finite and > 0)", i, f.expo);
                 if (f.kind == E_PAIR_ADJ && (f.k == 0 || f.k >= u))

@@ -60,6 +60,75 @@ def product_net(seed=0):
     return [sb0, N.Layer(l0), N.IdentityNode(24), rand_pca(rng, 24, 10)]
 
 
+def product_hier_net(seed=0, side=64):
+    """A hierarchy of realistic size with product expansions in every layer: side x side input, 4x4 fields (256 nodes at
+    side 64), then pair merges down to one node; node = whitening PCA -> [x, QT of the first 6, adjacent pair products] ->
+    SFA.  Used to compare the fused and the generic plan at BASELINE batch sizes."""
+    rng = np.random.default_rng(seed)
+    dims = [(10, 12), (14, 16), (16, 20), (20, 24), (24, 24), (24, 24), (24, 24), (24, 20)]
+    flow, c, w, h = [], 1, side, side
+    for li, (p, s_out) in enumerate(dims):
+        field = (4, 4) if li == 0 else ((2, 1) if (li % 2 == 1 and w > 1) or h == 1 else (1, 2))
+        sb = N.Rectangular2dSwitchboard((w, h), field, field, c)
+        funcs = [N.identity, N.sel_exp(6, N.QT), N.pair_prodsadj1_ex, N.unsigned_08expo]
+        nodes = []
+        for _ in range(sb.output_channels):
+            ex = N.GeneralExpansionNode(funcs, p)
+            nodes.append(N.FlowNode([rand_pca(rng, sb.out_channel_dim, p, N.WhiteningNode), ex, N.CutoffNode(ex.output_dim, -4.0, 4.0),
+                                     rand_sfa(rng, ex.output_dim, s_out)]))      # the clip keeps the untrained products bounded
+        flow += [sb, N.Layer(nodes)]
+        w, h = sb.out_channels_xy
+        c = s_out
+        if w * h == 1:
+            break
+    return flow
+
+
+def fuzz_product_net(seed):
+    """Random hierarchy whose expansions contain cross-column products (QT, pair_prodsadj*, sel_exp of them) next to
+    element-wise functions, uneven node widths, optional CutoffNode after the expansion and HeadNode after the node."""
+    rng = np.random.default_rng(7000 + seed)
+    w, h = (int(v) for v in rng.choice([4, 6, 8], 2))
+    flow, c = [], 1
+    for depth in range(int(rng.integers(1, 4))):
+        fx, fy = ((int(v) for v in rng.choice([2, 3, 4], 2)) if depth == 0 else [(2, 1), (1, 2), (2, 2)][int(rng.integers(0, 3))])
+        fx, fy = min(fx, w), min(fy, h)
+        while w % fx:
+            fx -= 1
+        while h % fy:
+            fy -= 1
+        sb = N.Rectangular2dSwitchboard((w, h), (fx, fy), (fx, fy), c)
+        n_nodes, d_in = sb.output_channels, sb.out_channel_dim
+        p0 = int(rng.integers(3, min(d_in, 12) + 1))
+        s0 = int(rng.integers(2, 30))
+        pool = [N.identity, N.QT, N.pair_prodsadj1_ex, N.pair_prodsadj2_ex, N.unsigned_08expo, N.signed_expo(float(rng.uniform(0.6, 1.2))),
+                N.sel_exp(int(rng.integers(2, p0)), N.QT), N.sel_exp(int(rng.integers(3, p0 + 1)), N.pair_prodsadj1_ex), N.pair_prodsadj_ex(2)]
+        nf = int(rng.integers(2, 6))
+        funcs = [pool[int(i)] for i in rng.choice(len(pool), nf, replace=False)]
+        if not any(f.kind in ("quadratic", "pair_adj") for f in funcs):
+            funcs[-1] = N.QT
+        uneven = rng.random() < 0.4
+        clip = rng.random() < 0.4
+        lo, hi = (-float(rng.uniform(1.5, 4.0)), float(rng.uniform(1.5, 4.0)))
+
+        def make(k):
+            p = max(3, p0 - (k % 2)) if uneven else p0
+            ex = N.GeneralExpansionNode(funcs, p)
+            seq = [rand_pca(rng, d_in, p, N.WhiteningNode if rng.random() < 0.5 else N.PCANode), ex]
+            if clip:
+                seq.append(N.CutoffNode(ex.output_dim, lo, hi))
+            seq.append(rand_sfa(rng, ex.output_dim, s0 + 2))
+            seq.append(N.HeadNode(s0 + 2, s0))
+            return N.FlowNode(seq)
+
+        flow += [sb, N.Layer([make(k) for k in range(n_nodes)])]
+        w, h = sb.out_channels_xy
+        c = s0
+        if w * h == 1:
+            break
+    return flow
+
+
 def wide_merge_net(seed=0):
     """A layer whose nodes merge 40 children of 13 features each (520 inputs -> 40 K-blocks x 4 tiles of
     weights = 160+ KiB per node): beyond what a workgroup's LDS holds, so the loader must pick the generic plan."""

@@ -59,8 +59,11 @@ def test_plans(native_lib, nets, monkeypatch):
     assert inf.plan_kind == _capi.HG_PLAN_FUSED and "fused gather" in desc and "fused iGSFA stage" in desc
     assert "folded" not in desc
     monkeypatch.delenv("HIGSFA_IG_NOFOLD")
+    # product expansions (QT, pair products), HeadNode, CutoffNode after the expansion: table-driven fused stage
     inf, desc = Flow(helpers.product_net()).host_plan()
-    assert inf.plan_kind == _capi.HG_PLAN_GENERIC and "fused plan not used" in desc
+    assert inf.plan_kind == _capi.HG_PLAN_FUSED and "table-driven expansion: products, clip" in desc and "fused gather" in desc
+    inf, desc = Flow(helpers.fuzz_product_net(3)).host_plan()
+    assert inf.plan_kind == _capi.HG_PLAN_FUSED and "table-driven expansion" in desc
     assert Flow(nets("T5L-16"), force_generic=True).host_plan()[0].plan_kind == _capi.HG_PLAN_GENERIC
     inf, desc = Flow(helpers.wide_merge_net()).host_plan()      # too much weight per node for LDS -> generic, with a reason
     assert inf.plan_kind == _capi.HG_PLAN_GENERIC and "LDS" in desc
@@ -128,15 +131,18 @@ def test_malformed_expansion_records_are_rejected(native_lib):
 
     cases = [patched(N.pair_prodsadj1_ex, k=0xFFFFFFFF),        # x_i * x_{i-1}: reads below the block
              patched(N.pair_prodsadj1_ex, k=0), patched(N.pair_prodsadj1_ex, k=8),
-             patched(N.QT, sel=0xFFFFFFFE), patched(N.QT, sel=9),
+             patched(N.sel_exp(3, N.QT), sel=5),                 # selection changed, output width no longer matches
              patched(N.unsigned_08expo, expo=float("nan")), patched(N.unsigned_08expo, expo=-0.5),
              patched(N.signed_08expo, expo=float("inf"))]
     for b in cases:
         rc, h = _load(native_lib, b)
         assert rc in (_capi.HG_ERR_FORMAT, _capi.HG_ERR_DIM), native_lib.hg_last_error()
         assert b"expansion" in native_lib.hg_last_error()
-    for ok in (net(N.pair_prodsadj1_ex), net(N.QT), net(N.sel_exp(3, N.QT)), net(N.unsigned_expo(1.3))):
-        rc, h = _load(native_lib, blob.flow_to_blob(ok))
+    good = [blob.flow_to_blob(x) for x in (net(N.pair_prodsadj1_ex), net(N.QT), net(N.sel_exp(3, N.QT)), net(N.unsigned_expo(1.3)))]
+    # a selection wider than the block reads all of it (numpy slicing clamps; cuicuilco's sel_exp): 9 of 8, 0xFFFFFFFE of 8
+    good += [patched(N.QT, sel=9), patched(N.QT, sel=0xFFFFFFFE)]
+    for b in good:
+        rc, h = _load(native_lib, b)
         assert rc == 0, native_lib.hg_last_error()
         native_lib.hg_flow_free(h)
 
