@@ -42,6 +42,10 @@ using namespace fused;
 struct FusedOptions {
     bool no_rem4 = false, ig_nofold = false, ig_resident = false, debug = false, no_prefetch_all = false;
     int split = 1, stamp_stage = -1, ig_w = 0, ig_t = 0;
+    // batches of up to this many 16-row tiles run the top layers as one persistent launch (0: never).  Measured on U11L-128
+    // (tools/small_batch2.py): 5-10 % of a call up to N = 128, a loss from N = 340 (one workgroup per node and slice cannot
+    // match the per-layer kernels' throughput), so the default stops at 8 tiles.
+    int chain_max_tiles = 8;
     static FusedOptions from_env() {
         FusedOptions o;
         o.no_rem4 = getenv("HIGSFA_NO_REM4") != nullptr;
@@ -52,6 +56,7 @@ struct FusedOptions {
         if (const char* e = getenv("HIGSFA_SPLIT")) o.split = std::max(1, std::min(4, atoi(e)));
         if (const char* e = getenv("HIGSFA_STAMP")) o.stamp_stage = atoi(e);
         if (const char* e = getenv("HIGSFA_IG_SHAPE")) sscanf(e, "%d,%d", &o.ig_w, &o.ig_t);
+        if (const char* e = getenv("HIGSFA_CHAIN_MAX_TILES")) o.chain_max_tiles = std::max(0, atoi(e));
         return o;
     }
 };
@@ -1024,6 +1029,7 @@ public:
                << " blocks/tile";
             hs.name = os.str();
         }
+        plan_chain();
         fuse01_ = can_fuse01();
         if (fuse01_) {
             stages_[0].name += "  [+ stage 1 fused in the same persistent kernel when the input allows 16-byte loads]";
@@ -1071,6 +1077,10 @@ public:
             }
         }
         d_col_base_.upload(col_base_.data(), col_base_.size() * 4);
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            n_cus_ = prop.multiProcessorCount;
     }
 
     void reserve(int64_t rows) override {
@@ -1152,6 +1162,14 @@ public:
                 }
                 return R;
             };
+            if (chain_begin_ >= 0 && (int)si == chain_begin_ && n_tiles <= opt_.chain_max_tiles) {
+                run_chain(n_tiles, cur, nxt, st);           // reads `cur`, final layer writes `nxt`, the layers between their own regions
+                const int nc = (int)stages_.size() - chain_begin_;
+                std::swap(cur, nxt);
+                if (ev)
+                    for (int k = 0; k < nc; ++k) HG_HIP(hipEventRecord(ev[e++], st));   // first event carries the chain's time
+                break;
+            }
             StageParams P = base_params(s, cur, nxt);
             if (s.kind == 1) {        // row-major input -> fragment order
                 const size_t esz0 = dtype_size(x_dtype), al0 = x_dtype == HG_U8 ? 4 : 16;
@@ -1428,6 +1446,8 @@ public:
         fork_ = nullptr;
         bufA_.free();
         bufB_.free();
+        chain_buf_.free();
+        chain_flags_.free();
         d_col_base_.free();
         for (auto& s : stages_) {
             s.d_afrag.free(); s.d_bias.free(); s.d_kb1tab.free(); s.d_chunks.free();
@@ -2052,6 +2072,91 @@ private:
         hipLaunchKernelGGL(fn, (unsigned)blocks, nw * 64, lds_bytes, st, P);
     }
 
+    // The suffix of the stage list that k_chain (hg_fused_chain.hip) can run as one launch: ordinary layers of <= 16 nodes with
+    // one tile shape, at least two of them.
+    void plan_chain() {
+        chain_begin_ = -1;
+        if (opt_.chain_max_tiles <= 0 || stages_.size() < 3) return;
+        const HostStage& top = stages_.back();
+        int b = (int)stages_.size();
+        int sum_nodes = 0;
+        while (b > 1) {
+            const HostStage& s = stages_[b - 1];
+            if (s.kind != 0 || s.from_x || s.rem4 || s.n_nodes > 16 || s.kb1 > 8 || s.nf > kMaxFuncs) break;
+            if (s.mt1 != top.mt1 || (s.has_exp ? s.mt2 : top.mt2) != top.mt2 || s.has_exp != top.has_exp) break;
+            if (chain_lds_bytes(s.node_blocks, s.bias_floats, s.mt1, std::max(1, s.nf)) > 150 * 1024) break;
+            if ((int)stages_.size() - (b - 1) > kMaxChain || sum_nodes + s.n_nodes > 128) break;
+            sum_nodes += s.n_nodes;
+            --b;
+        }
+        if ((int)stages_.size() - b < 2 || !chain_supported(top.mt1, top.has_exp ? top.mt2 : top.mt1)) return;
+        chain_begin_ = b;
+        for (size_t i = b; i < stages_.size(); ++i) stages_[i].name += i == (size_t)b ? "  [small batches: this and the layers above run as one persistent launch]" : "  [in the persistent launch for small batches]";
+    }
+
+    void run_chain(int n_tiles, f32x4* cur, f32x4* nxt, hipStream_t st) {
+        const int nc = (int)stages_.size() - chain_begin_;
+        ChainParams C{};
+        C.n_stages = nc;
+        C.n_tiles = n_tiles;
+        C.tiles_per_group = 2;
+        C.n_groups = (n_tiles + 1) / 2;
+        int sum_nodes = 0;
+        size_t lds = 0, region = 0;
+        for (int k = 0; k < nc; ++k) sum_nodes += stages_[chain_begin_ + k].n_nodes;
+        C.slices = std::max(1, std::min(C.n_groups, n_cus_ / std::max(1, sum_nodes)));
+        // every layer but the last writes a region of its own
+        for (int k = 0; k + 1 < nc; ++k) region += (size_t)n_tiles * stages_[chain_begin_ + k].nb_out * 1024;
+        if (chain_buf_.bytes < region) chain_buf_.alloc(region);
+        const size_t fbytes = ((size_t)nc * C.n_groups * 16 + 16) * 4;
+        if (chain_flags_.bytes < fbytes) {
+            chain_flags_.alloc(fbytes * 2);
+            HG_HIP(hipMemset(chain_flags_.p, 0, chain_flags_.bytes));      // generation 0 is never published
+        }
+        C.flags = (uint32_t*)chain_flags_.p + 16;
+        C.err = (int32_t*)chain_flags_.p;
+        C.gen = ++chain_gen_;
+        if (chain_gen_ == 0xffffffffu) {      // wrap: start over with clean flags
+            HG_HIP(hipMemsetAsync(chain_flags_.p, 0, chain_flags_.bytes, st));
+            chain_gen_ = 0;
+            C.gen = ++chain_gen_;
+        }
+        f32x4* final_out = nxt;       // never the buffer the chain's first layer still reads
+        char* reg = (char*)chain_buf_.p;
+        const f32x4* in = cur;
+        int wg = 0;
+        for (int k = 0; k < nc; ++k) {
+            HostStage& hs = stages_[chain_begin_ + k];
+            ChainStage& S = C.st[k];
+            S.afrag = (const f32x4*)hs.d_afrag.p;
+            S.bias = (const float*)hs.d_bias.p;
+            S.kb1tab = (const int2*)hs.d_kb1tab.p;
+            S.in = in;
+            S.out = k + 1 < nc ? (f32x4*)reg : final_out;
+            S.n_nodes = hs.n_nodes;
+            S.kb1 = hs.kb1;
+            S.nf = hs.nf;
+            S.has_exp = hs.has_exp ? 1 : 0;
+            S.node_blocks = hs.node_blocks;
+            S.bias_floats = hs.bias_floats;
+            S.nb_in = hs.nb_in;
+            S.nb_out = hs.nb_out;
+            S.mto = hs.mto;
+            S.wg_begin = wg;
+            for (int fi = 0; fi < hs.nf; ++fi) {
+                S.funcp |= (uint32_t)hs.funcs[fi].kind << (4 * fi);
+                S.expo[fi] = (float)hs.funcs[fi].expo;
+                for (int mt1 = 0; mt1 < hs.mt1; ++mt1) S.nk2p[mt1] |= (uint32_t)hs.nk2[mt1][fi] << (4 * fi);
+            }
+            wg += hs.n_nodes * C.slices;
+            lds = std::max(lds, chain_lds_bytes(hs.node_blocks, hs.bias_floats, hs.mt1, std::max(1, hs.nf)));
+            in = (const f32x4*)reg;
+            reg += (size_t)n_tiles * hs.nb_out * 1024;
+        }
+        const HostStage& top = stages_.back();
+        launch_chain(C, top.mt1, top.has_exp ? top.mt2 : top.mt1, wg, lds, st);
+    }
+
     // Layers 0 and 1 can share one kernel when a wave's two layer-0 node slots are exactly the two
     // children of one layer-1 node (see k_stage01p).
     bool can_fuse01() const {
@@ -2087,6 +2192,9 @@ private:
     std::map<std::tuple<const void*, int, size_t>, int> occ_;
     int max_nb_ = 0;
     int64_t padded_flops_ = 0, cap_rows_ = 0;
+    int chain_begin_ = -1, n_cus_ = 256;      // first stage of the persistent top-of-hierarchy launch (-1: none)
+    uint32_t chain_gen_ = 0;
+    DevBuf chain_buf_, chain_flags_;
 };
 
 }  // namespace

@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "hg_common.hpp"
 
 namespace hg {
@@ -212,6 +214,29 @@ __device__ __forceinline__ void node_tail(const StageParams& P, WP wA2, BP b2, i
             if (tile[t] < P.n_tiles) P.out[((size_t)tile[t] * P.nb_out + out_blk + mt) * 64 + lane] = y[mt][t];
 }
 
+
+// k_chain (hg_fused_chain.hip): the layers at the top of the hierarchy as one persistent launch
+struct ChainStage {
+    const f32x4* afrag;
+    const float* bias;
+    const int2* kb1tab;
+    const f32x4* in;
+    f32x4* out;
+    int32_t n_nodes, kb1, nf, has_exp, node_blocks, bias_floats, nb_in, nb_out, mto, wg_begin;
+    uint32_t nk2p[kMaxMT], funcp;
+    float expo[kMaxFuncs];
+};
+constexpr int kMaxChain = 6;
+struct ChainParams {
+    ChainStage st[kMaxChain];
+    int32_t n_stages, n_tiles, tiles_per_group, n_groups, slices;
+    uint32_t gen;
+    uint32_t* flags;      // [stage][group][16]: generation number of the launch that published (stage, group, node)
+    int32_t* err;
+};
+bool chain_supported(int mt1, int mt2);
+size_t chain_lds_bytes(int node_blocks, int bias_floats, int mt1, int nf);
+void launch_chain(const ChainParams& C, int mt1, int mt2, int grid, size_t lds, hipStream_t st);
 
 typedef void (*StageFn)(StageParams);
 typedef void (*StageFn2)(StageParams, StageParams);

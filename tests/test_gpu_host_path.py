@@ -103,3 +103,31 @@ def test_batch_size_dependence_is_bounded(native_lib, nets):
         assert d <= 2e-6, (n, d)
     assert np.array_equal(flow.execute(x[:728], n_cols=20), flow.execute(x[:728], n_cols=20))
     flow.close()
+
+
+def test_persistent_top_of_hierarchy_launch(native_lib, nets, monkeypatch):
+    """Small batches (N <= 128) run the last layers of U11L-128 (16, 8, 4, 2, 1 nodes) as ONE persistent launch whose
+    workgroups hand tile groups from layer to layer through memory (hg_fused_chain.hip).  Same bits as the per-layer
+    kernels; flags carry a generation number, so repeated calls and alternating batch sizes never see a stale hand-off."""
+    nodes = nets("U11L-128")
+    x = synth.make_subimages(300, 128, dtype=np.uint8)
+    chain = Flow(nodes, output_dtype=np.float32)
+    assert "one persistent launch" in chain.describe()
+    monkeypatch.setenv("HIGSFA_CHAIN_MAX_TILES", "0")
+    layers = Flow(nodes, output_dtype=np.float32)
+    assert "persistent launch" not in layers.describe()
+    monkeypatch.delenv("HIGSFA_CHAIN_MAX_TILES")
+    for n in (1, 16, 17, 128, 100, 1, 300, 33, 128):          # 300 > 128: both take the per-layer kernels
+        a, b = chain.execute(x[:n]), layers.execute(x[:n])
+        assert a.shape == (n, 60) and np.array_equal(a, b), n
+    ref = oracle.execute_flow(nodes, x[:33])
+    assert rel_err(chain.execute(x[:33]), ref) <= TOL
+    for _ in range(50):                                        # many launches back to back: generations 10 .. 60
+        assert np.array_equal(chain.execute(x[:100]), b[:100] if False else layers.execute(x[:100]))
+    # the chain with a forced larger reach (tile groups spread over slices of every node)
+    monkeypatch.setenv("HIGSFA_CHAIN_MAX_TILES", "64")
+    wide = Flow(nodes, output_dtype=np.float32)
+    for n in (300, 728, 1000):
+        assert np.array_equal(wide.execute(x[:n] if n <= 300 else np.tile(x, (4, 1))[:n]), layers.execute(x[:n] if n <= 300 else np.tile(x, (4, 1))[:n])), n
+    for f in (chain, layers, wide):
+        f.close()
