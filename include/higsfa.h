@@ -204,6 +204,34 @@ int hg_cascade_compact_device(int device, const uint8_t* discard_dev, int64_t n,
 int hg_gather_rows_device(int device, const void* src_dev, void* dst_dev, int64_t row_bytes, const int32_t* map_dev,
                           const int32_t* count_dev, int64_t n_max, void* stream);
 
+/* The whole stage loop (FaceDetectUpdated.py:665-766) of one batch of first-stage windows as ONE host call: for every stage
+ * extract (rotated by -angle, unless the previous stage was a Disc stage or the stage has no network, :674-681) -> the stage's
+ * flow (hg_flow_execute_device; NULL = reuse the previous features, the pipeline's "None0") -> regression -> coordinate update,
+ * discard test, compaction (one fused kernel).  No per-candidate array visits the host; the host reads the survivor count only
+ * after Disc stages (where it shrinks a lot and sizes the next launches) — between them launches are sized by the last count
+ * read and the kernels take the exact count from device memory.  All pyramid levels may be one batch (:599).
+ * flow / classifier handles stay owned by the caller and must live on `device`. */
+typedef struct hg_gauss hg_gauss;
+typedef struct hg_cascade hg_cascade;
+typedef struct hg_cascade_stage {
+    int32_t type;            /* enum hg_stage_type                                                   */
+    int32_t serial;          /* trailing digit of the stage name: index into cut_offs_face (:669-672) */
+    hg_flow* flow;           /* NULL: networks[k] is None                                            */
+    hg_gauss* classifier;
+} hg_cascade_stage;
+int hg_cascade_create(const hg_cascade_stage* stages, int n_stages, int sub_w, int sub_h, int n_features,
+                      const hg_cascade_consts* consts, const double* cut_offs_face, int n_cut_offs, int device,
+                      hg_cascade** out);
+void hg_cascade_free(hg_cascade* c);
+/* frame_dev: (frame_h, frame_w) uint8 on the device, row stride ld; boxes_host (n0, 4) / level_host (n0, 3): the first-stage
+ * windows and their level constants.  Outputs (host, room for out_cap detections): final coordinates, angles, index of the
+ * original window, Disc confidence; *n_out detections; stage_counts[n_stages] survivors after each stage (-1 where the count
+ * was not read back); *rows_executed rows pushed through flows.  Synchronous. */
+int hg_cascade_detect_device(hg_cascade* c, const void* frame_dev, int frame_h, int frame_w, int64_t ld,
+                             const double* boxes_host, const double* level_host, int64_t n0, double* out_coords,
+                             double* out_angles, int32_t* out_orig_index, double* out_confidence, int64_t out_cap,
+                             int64_t* n_out, int32_t* stage_counts, int64_t* rows_executed, void* stream);
+
 /* --- SFA training step for one layer of nodes (BASELINE.json configs[4]) -----
  * Not on the reference's path (it never trains, face_analysis.py:451-479); restates
  * mdp.nodes.SFANode train/stop_training per node k over input columns conn[k*d .. (k+1)*d):

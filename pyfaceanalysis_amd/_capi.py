@@ -29,6 +29,10 @@ class HgCascadeConsts(C.Structure):
         "tolerance_angle_deviation", "max_scale_radio", "min_scale_radio", "net_Dang", "cut_off_face")]
 
 
+class HgCascadeStage(C.Structure):
+    _fields_ = [("type", C.c_int32), ("serial", C.c_int32), ("flow", C.c_void_p), ("classifier", C.c_void_p)]
+
+
 HG_STAGE = {"Disc": 0, "PosX": 1, "PosY": 2, "PAng": 3, "Scale": 4}
 
 
@@ -87,6 +91,9 @@ def lib():
         "hg_cascade_update_device": (C.c_int, [i32, i32, C.POINTER(HgCascadeConsts), i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         "hg_cascade_compact_device": (C.c_int, [i32, vp, i64, vp, vp, vp]),
         "hg_gather_rows_device": (C.c_int, [i32, vp, vp, i64, vp, vp, i64, vp]),
+        "hg_cascade_create": (C.c_int, [C.POINTER(HgCascadeStage), i32, i32, i32, i32, C.POINTER(HgCascadeConsts), vp, i32, i32, C.POINTER(vp)]),
+        "hg_cascade_free": (None, [vp]),
+        "hg_cascade_detect_device": (C.c_int, [vp, vp, i32, i32, i64, vp, vp, i64, vp, vp, vp, vp, i64, C.POINTER(i64), vp, C.POINTER(i64), vp]),
         "hg_sfa_train_layer": (C.c_int, [vp, i32, i32, i64, i64, vp, C.c_int32, C.c_int32, i32, vp, vp, vp, vp]),
     }
     for name, (res, args) in sigs.items():
@@ -104,7 +111,8 @@ EXPORTED_SYMBOLS = (
     "hg_flow_reset_profile", "hg_gauss_create", "hg_gauss_free", "hg_gauss_regression_device",
     "hg_gauss_regression", "hg_patcher_create", "hg_patcher_free", "hg_patcher_extract_device",
     "hg_patcher_extract", "hg_patcher_extract_rotate_device", "hg_patcher_extract_rotate", "hg_cascade_update_device",
-    "hg_cascade_compact_device", "hg_gather_rows_device", "hg_sfa_train_layer",
+    "hg_cascade_compact_device", "hg_gather_rows_device", "hg_cascade_create", "hg_cascade_free", "hg_cascade_detect_device",
+    "hg_sfa_train_layer",
 )
 
 _EXC = {HG_ERR_ARG: ValueError, HG_ERR_FORMAT: ValueError, HG_ERR_DIM: ValueError,

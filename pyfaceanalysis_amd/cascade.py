@@ -8,12 +8,13 @@ The reference runs, per image, per pyramid level and per cascade stage (FaceDete
     update_current_subimage_coordinates / identify_patches_to_discard :728-735 (face_analysis.py:803-887)
     boolean-mask compaction of every per-candidate array              :739-759
 
-``DeviceCascade`` chains the same steps through the C ABI (``hg_patcher_extract_rotate_device`` ->
-``hg_flow_execute_device`` -> ``hg_gauss_regression_device`` -> ``hg_cascade_update_device`` ->
-``hg_cascade_compact_device`` / ``hg_gather_rows_device``) on one stream: no per-candidate array ever visits the
-host; the host reads one integer per stage (the survivor count, needed to size the next launches).  All pyramid
-levels run as ONE batch of candidates, as the reference's author notes is possible (:599), each candidate carrying its
-level's constants.  torch is used for device buffers and the stream only.
+``DeviceCascade`` runs the same loop inside the library (``hg_cascade_detect_device``, include/higsfa.h: rotated window
+extraction -> ``hg_flow_execute_device`` -> Gaussian regression -> one fused update / discard / compaction kernel per stage)
+on one stream: no per-candidate array ever visits the host; the host reads one integer after each Disc stage (the survivor
+count, which shrinks a lot there and sizes the next launches).  All pyramid levels run as ONE batch of candidates, as the
+reference's author notes is possible (:599), each candidate carrying its level's constants.  torch is used for the frame
+tensor and the stream only.  (The single steps are also exported one by one — ``hg_cascade_update_device``,
+``hg_cascade_compact_device``, ``hg_gather_rows_device`` — for callers that drive the loop themselves.)
 
 Stages follow the pipeline grammar (face_analysis.py:437-443): a type with a serial digit ("Disc1", "PosX0", ...), a flow
 or None (the stage reuses the previous features, :680-682), a classifier.
@@ -67,13 +68,12 @@ class DeviceCascade(object):
         self.device = int(device)
         self.dev = torch.device("cuda", self.device)
         self.patcher = Patcher(self.device)
-        self.cap = 0
+        self._h = None
         for st in self.stages:
             if st.classifier.input_dim > self.k:
                 raise ValueError("stage %s: classifier reads %d features, cascade keeps %d" % (st.name, st.classifier.input_dim, self.k))
-        self._pinned_count = torch.zeros(1, dtype=torch.int32).pin_memory()
 
-    def _consts(self, serial):
+    def _consts(self):
         p = self.pipeline
         c = _capi.HgCascadeConsts()
         c.regression_width, c.regression_height = p["regression_width"], p["regression_height"]
@@ -81,29 +81,29 @@ class DeviceCascade(object):
         c.tolerance_posxy_deviation, c.tolerance_scale_deviation, c.tolerance_angle_deviation = TOLERANCE_POSXY, TOLERANCE_SCALE, TOLERANCE_ANGLE
         c.max_scale_radio, c.min_scale_radio = p["net_maxs"] / 0.825, p["net_mins"] / 0.825
         c.net_Dang = p["net_Dang"]
-        c.cut_off_face = CUT_OFFS_FACE[serial]
+        c.cut_off_face = 0.0                 # per stage: cut_offs_face[serial]
         return c
 
-    def _reserve(self, n0):
-        if n0 <= self.cap:
-            return
-        t, d = self.torch, self.dev
-        pp = lambda *shape, dtype: [t.empty(shape, dtype=dtype, device=d) for _ in range(2)]     # ping-pong pairs
-        self.coords, self.angles = pp(n0, 4, dtype=t.float64), pp(n0, dtype=t.float64)
-        self.oidx, self.conf = pp(n0, dtype=t.int32), pp(n0, dtype=t.float64)
-        self.sl, self.subs = pp(n0, self.k, dtype=t.float32), pp(n0, self.w * self.h, dtype=t.uint8)
-        self.reg = t.empty(n0, dtype=t.float64, device=d)
-        self.discard = t.empty(n0, dtype=t.uint8, device=d)
-        self.map = t.empty(n0, dtype=t.int32, device=d)
-        self.count = t.zeros(1, dtype=t.int32, device=d)
-        self.orig_coords = t.empty((n0, 4), dtype=t.float64, device=d)
-        self.orig_level = t.empty((n0, 3), dtype=t.float64, device=d)
-        self.orig_angles = t.zeros(n0, dtype=t.float64, device=d)
-        self.neg = t.empty(n0, dtype=t.float64, device=d)
-        self.cap = n0
-        for st in self.stages:
+    def _handle(self):
+        if self._h is not None:
+            return self._h
+        L = _capi.lib()
+        arr = (_capi.HgCascadeStage * len(self.stages))()
+        for i, st in enumerate(self.stages):
+            arr[i].type, arr[i].serial = _capi.HG_STAGE[st.type], st.serial
             if st.flow is not None:
-                st.flow.reserve(n0)
+                if st.flow.device != self.device or st.flow.output_dtype != np.float32:
+                    raise ValueError("stage %s: flow must live on device %d with output_dtype float32" % (st.name, self.device))
+                arr[i].flow = st.flow._handle().h
+            else:
+                arr[i].flow = None
+            arr[i].classifier = st.classifier._handle(st.classifier.avg_labels)
+        cut = (C.c_double * len(CUT_OFFS_FACE))(*CUT_OFFS_FACE)
+        cc = self._consts()
+        h = C.c_void_p()
+        _capi.check(L.hg_cascade_create(arr, len(self.stages), self.w, self.h, self.k, C.byref(cc), cut, len(CUT_OFFS_FACE), self.device, C.byref(h)))
+        self._h = h
+        return h
 
     def prescale(self, frame, prescale_size=grid.PRESCALE_SIZE):
         """FaceDetectUpdated.py:551-556: shrink so that the larger side is <= prescale_size, ``Image.resize(NEAREST)`` —
@@ -122,63 +122,30 @@ class DeviceCascade(object):
 
     def detect(self, frame, smallest_face=0.2, windows=None):
         """frame: (H, W) uint8 torch tensor on this device.  Returns a dict of host arrays: coords (n, 4), angles (n),
-        orig_index (n), confidence (n), counts (survivors after every stage), rows_executed."""
+        orig_index (n), confidence (n), counts (survivors after every stage, -1 where the count stayed on the device),
+        rows_executed."""
         t, L = self.torch, _capi.lib()
         fh, fw = int(frame.shape[0]), int(frame.shape[1])
         if frame.dtype != t.uint8 or frame.device != self.dev or frame.stride(1) != 1:
             raise ValueError("frame must be a uint8 tensor on %s with contiguous rows" % (self.dev,))
         boxes, level = frame_windows(fw, fh, smallest_face, self.pipeline, (self.w, self.h)) if windows is None else windows
-        n = n0 = len(boxes)
-        self._reserve(n0)
-        stream = t.cuda.current_stream(self.dev)
-        sp = stream.cuda_stream
-        self.orig_coords[:n0].copy_(t.from_numpy(np.ascontiguousarray(boxes)), non_blocking=True)
-        self.orig_level[:n0].copy_(t.from_numpy(np.ascontiguousarray(level)), non_blocking=True)
-        cur = 0
-        self.coords[cur][:n0].copy_(self.orig_coords[:n0])
-        self.angles[cur][:n0].zero_()
-        self.oidx[cur][:n0].copy_(t.arange(n0, dtype=t.int32, device=self.dev))
-        self.conf[cur][:n0].zero_()
-        counts, rows_executed = [], 0
-        vp = lambda x: C.c_void_p(x.data_ptr())
-        for k, st in enumerate(self.stages):
-            if n == 0:
-                counts.append(0)
-                continue
-            skip_extract = (k > 0 and self.stages[k - 1].type == "Disc") or st.flow is None          # FaceDetectUpdated.py:674-681
-            if not skip_extract:
-                t.neg(self.angles[cur][:n], out=self.neg[:n])                                         # -1 * curr_angles (face_analysis.py:782)
-                self.patcher.extract_device(frame.data_ptr(), np.uint8, fh, fw, frame.stride(0), self.coords[cur].data_ptr(), n,
-                                            (self.w, self.h), self.subs[cur].data_ptr(), np.uint8, self.w * self.h, stream=sp,
-                                            delta_angs_ptr=self.neg.data_ptr())
-            if st.flow is not None:
-                st.flow.execute_device(self.subs[cur].data_ptr(), np.uint8, n, self.w * self.h, self.sl[cur].data_ptr(), np.float32,
-                                       self.k, self.k, stream=sp)
-                rows_executed += n
-            st.classifier.regression_device(self.sl[cur].data_ptr(), np.float32, n, self.k, self.reg.data_ptr(), stream=sp)
-            cc = self._consts(st.serial)
-            _capi.check(L.hg_cascade_update_device(self.device, _capi.HG_STAGE[st.type], C.byref(cc), n, vp(self.coords[cur]), vp(self.angles[cur]),
-                                                   vp(self.reg), vp(self.oidx[cur]), vp(self.orig_coords), vp(self.orig_angles),
-                                                   vp(self.orig_level), vp(self.discard), C.c_void_p(sp)))
-            _capi.check(L.hg_cascade_compact_device(self.device, vp(self.discard), n, vp(self.map), vp(self.count), C.c_void_p(sp)))
-            nxt = 1 - cur
-            rows = [(self.coords, 32), (self.angles, 8), (self.oidx, 4), (self.sl, 4 * self.k)]
-            # the sub-images are reused only by a stage that follows a Disc stage and has a flow of its own (:674-677)
-            if st.type == "Disc" and k + 1 < len(self.stages) and self.stages[k + 1].flow is not None:
-                rows.append((self.subs, self.w * self.h))
-            for buf, rb in rows:
-                _capi.check(L.hg_gather_rows_device(self.device, vp(buf[cur]), vp(buf[nxt]), rb, vp(self.map), vp(self.count), n, C.c_void_p(sp)))
-            src_conf = self.reg if st.type == "Disc" else self.conf[cur]                               # :758-759
-            _capi.check(L.hg_gather_rows_device(self.device, vp(src_conf), vp(self.conf[nxt]), 8, vp(self.map), vp(self.count), n, C.c_void_p(sp)))
-            cur = nxt
-            self._pinned_count.copy_(self.count, non_blocking=True)        # the one host readback of the stage
-            stream.synchronize()
-            n = int(self._pinned_count[0])
-            counts.append(n)
-        out = dict(coords=self.coords[cur][:n].cpu().numpy(), angles=self.angles[cur][:n].cpu().numpy(),
-                   orig_index=self.oidx[cur][:n].cpu().numpy().astype(np.int64), confidence=self.conf[cur][:n].cpu().numpy(),
-                   counts=counts, rows_executed=rows_executed, n_windows=n0)
-        return out
+        boxes = np.ascontiguousarray(boxes, dtype=np.float64)
+        level = np.ascontiguousarray(level, dtype=np.float64)
+        n0 = len(boxes)
+        coords, angles = np.empty((n0, 4)), np.empty(n0)
+        oidx, conf = np.empty(n0, dtype=np.int32), np.empty(n0)
+        counts = np.zeros(len(self.stages), dtype=np.int32)
+        n_out, rows = C.c_int64(), C.c_int64()
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        _capi.check(L.hg_cascade_detect_device(
+            self._handle(), C.c_void_p(frame.data_ptr()), fh, fw, frame.stride(0), vp(boxes), vp(level), n0, vp(coords), vp(angles), vp(oidx),
+            vp(conf), n0, C.byref(n_out), vp(counts), C.byref(rows), C.c_void_p(t.cuda.current_stream(self.dev).cuda_stream)))
+        n = n_out.value
+        return dict(coords=coords[:n].copy(), angles=angles[:n].copy(), orig_index=oidx[:n].astype(np.int64), confidence=conf[:n].copy(),
+                    counts=[int(c) for c in counts], rows_executed=int(rows.value), n_windows=n0)
 
     def close(self):
+        if self._h is not None:
+            _capi.lib().hg_cascade_free(self._h)
+            self._h = None
         self.patcher.close()

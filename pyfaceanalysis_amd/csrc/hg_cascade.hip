@@ -10,6 +10,8 @@
 // FaceDetectUpdated.py:599): the per-level constants max_Dx_diff, max_Dy_diff, base_side travel per ORIGINAL window.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "hg_common.hpp"
 
 namespace hg { void set_last_error(const std::string& s); }
@@ -130,6 +132,116 @@ __global__ void __launch_bounds__(256) k_gather_rows(const char* __restrict__ sr
     }
 }
 
+// One cascade stage's glue in ONE launch of ONE workgroup (a frame has at most a few thousand candidates): update + discard
+// test per candidate (same arithmetic as k_cascade_update), order-preserving compaction, and the gather of every small
+// per-candidate array into the other half of its ping-pong pair.  The candidate count comes from device memory (the previous
+// stage's output), so stages chain without a host round trip; the new count goes to device memory and, for the caller that
+// wants it, to a pinned host word.
+struct StageArrays {
+    double *coords[2], *angles[2], *conf[2], *neg_angles;   // [cur / nxt]
+    int32_t* oidx[2];
+    float* sl[2];
+    const double *reg, *orig_coords, *orig_angles, *orig_level;
+    uint8_t* discard;
+    int32_t* map;
+    int32_t *count_in, *count_out;
+    int32_t k_feat, cur, n_max;
+};
+
+__device__ __forceinline__ bool update_one(int type, const hg_cascade_consts& c, double& x0, double& y0, double& x1, double& y1, double& ang,
+                                            double r, const double* oc, double oa, const double* lvl) {
+    switch (type) {
+        case HG_STAGE_DISC: return r >= c.cut_off_face;
+        case HG_STAGE_POSX: {
+            const double ro = __ddiv_rn(__dmul_rn(r, __dsub_rn(x1, x0)), c.regression_width);
+            x0 = __dsub_rn(x0, ro);
+            x1 = __dsub_rn(x1, ro);
+            const double d = __dsub_rn(__ddiv_rn(__dadd_rn(x1, x0), 2.0), __ddiv_rn(__dadd_rn(oc[2], oc[0]), 2.0));
+            return fabs(d) > __dmul_rn(lvl[0], c.tolerance_posxy_deviation);
+        }
+        case HG_STAGE_POSY: {
+            const double ro = __ddiv_rn(__dmul_rn(r, __dsub_rn(y1, y0)), c.regression_height);
+            y0 = __dsub_rn(y0, ro);
+            y1 = __dsub_rn(y1, ro);
+            const double d = __dsub_rn(__ddiv_rn(__dadd_rn(y1, y0), 2.0), __ddiv_rn(__dadd_rn(oc[3], oc[1]), 2.0));
+            return fabs(d) > __dmul_rn(lvl[1], c.tolerance_posxy_deviation);
+        }
+        case HG_STAGE_PANG: {
+            ang = __dadd_rn(ang, r);
+            const double lim = __dmul_rn(c.net_Dang, c.tolerance_angle_deviation);
+            return ang > __dadd_rn(oa, lim) || ang < __dsub_rn(oa, lim);
+        }
+        default: {
+            const double ow = __dsub_rn(x1, x0), oh = __dsub_rn(y1, y0);
+            const double xc = __ddiv_rn(__dadd_rn(x1, x0), 2.0), yc = __ddiv_rn(__dadd_rn(y1, y0), 2.0);
+            const double w = __dmul_rn(__ddiv_rn(ow, r), c.desired_sampling), h = __dmul_rn(__ddiv_rn(oh, r), c.desired_sampling);
+            x0 = __dsub_rn(xc, __ddiv_rn(w, 2.0));
+            x1 = __dadd_rn(xc, __ddiv_rn(w, 2.0));
+            y0 = __dsub_rn(yc, __ddiv_rn(h, 2.0));
+            y1 = __dadd_rn(yc, __ddiv_rn(h, 2.0));
+            const double dx = __dsub_rn(x0, x1), dy = __dsub_rn(y0, y1);
+            const double ratio = __ddiv_rn(__dsqrt_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy))), lvl[2]);
+            return ratio > __dmul_rn(c.max_scale_radio, c.tolerance_scale_deviation) || ratio < __ddiv_rn(c.min_scale_radio, c.tolerance_scale_deviation);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(1024) k_cascade_stage(int type, hg_cascade_consts c, StageArrays A, int32_t* host_count) {
+    __shared__ int wsum[16];
+    __shared__ int base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = min(*A.count_in, A.n_max);
+    const int cur = A.cur, nxt = 1 - cur;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += blockDim.x) {
+        const int i = i0 + tid;
+        int keep = 0;
+        double x0 = 0, y0 = 0, x1 = 0, y1 = 0, ang = 0, r = 0;
+        int32_t oi = 0;
+        if (i < n) {
+            x0 = A.coords[cur][i * 4]; y0 = A.coords[cur][i * 4 + 1]; x1 = A.coords[cur][i * 4 + 2]; y1 = A.coords[cur][i * 4 + 3];
+            ang = A.angles[cur][i];
+            r = A.reg[i];
+            oi = A.oidx[cur][i];
+            keep = update_one(type, c, x0, y0, x1, y1, ang, r, A.orig_coords + (size_t)oi * 4, A.orig_angles[oi], A.orig_level + (size_t)oi * 3) ? 0 : 1;
+        }
+        const unsigned long long m = __ballot(keep);
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+        if (keep) {
+            const int j = off + before;
+            A.map[j] = i;
+            A.coords[nxt][j * 4] = x0; A.coords[nxt][j * 4 + 1] = y0; A.coords[nxt][j * 4 + 2] = x1; A.coords[nxt][j * 4 + 3] = y1;
+            A.angles[nxt][j] = ang;
+            A.neg_angles[j] = -ang;                                         // what the next extraction is called with (face_analysis.py:782)
+            A.oidx[nxt][j] = oi;
+            A.conf[nxt][j] = type == HG_STAGE_DISC ? r : A.conf[cur][i];     // FaceDetectUpdated.py:758-759
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int t = 0;
+            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += wsum[w];
+            base += t;
+        }
+        __syncthreads();
+    }
+    const int cnt = base;
+    // features of the survivors (map is complete: barriers above)
+    const int kf = A.k_feat;
+    for (int e = tid; e < cnt * kf; e += blockDim.x) {
+        const int j = e / kf, f = e - j * kf;
+        A.sl[nxt][(size_t)j * kf + f] = A.sl[cur][(size_t)A.map[j] * kf + f];
+    }
+    if (tid == 0) {
+        *A.count_out = cnt;
+        if (host_count) *host_count = cnt;
+    }
+}
+
 void set_dev(int device) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
@@ -183,6 +295,186 @@ int hg_gather_rows_device(int device, const void* src_dev, void* dst_dev, int64_
         hipLaunchKernelGGL(k_gather_rows, (unsigned)std::min<int64_t>(n_max, 16384), threads, 0, (hipStream_t)stream, (const char*)src_dev, (char*)dst_dev,
                            row_bytes, map_dev, count_dev, vec16);
         HG_HIP(hipGetLastError());
+    });
+}
+
+// ---- the whole stage loop as one host call ---------------------------------------------------------------------------
+struct hg_cascade {
+    int device = 0, w = 0, h = 0, k = 0;
+    std::vector<hg_cascade_stage> stages;
+    hg_cascade_consts base{};
+    double cut_offs[10];
+    hg_patcher* patcher = nullptr;
+    int64_t cap = 0;
+    hg::DevBuf coords[2], angles[2], conf[2], oidx[2], sl[2], subs[2], neg, reg, discard, map, count, orig_coords, orig_level, orig_angles;
+    int32_t* host_count = nullptr;       // pinned, device-visible
+
+    void reserve(int64_t n0) {
+        if (n0 <= cap) return;
+        for (int b = 0; b < 2; ++b) {
+            coords[b].alloc((size_t)n0 * 32);
+            angles[b].alloc((size_t)n0 * 8);
+            conf[b].alloc((size_t)n0 * 8);
+            oidx[b].alloc((size_t)n0 * 4);
+            sl[b].alloc((size_t)n0 * k * 4);
+            subs[b].alloc((size_t)n0 * w * h);
+        }
+        neg.alloc((size_t)n0 * 8);
+        reg.alloc((size_t)n0 * 8);
+        discard.alloc((size_t)n0);
+        map.alloc((size_t)n0 * 4);
+        count.alloc(16);
+        orig_coords.alloc((size_t)n0 * 32);
+        orig_level.alloc((size_t)n0 * 24);
+        orig_angles.alloc((size_t)n0 * 8);
+        HG_HIP(hipMemset(orig_angles.p, 0, (size_t)n0 * 8));
+        for (auto& st : stages)
+            if (st.flow && hg_flow_reserve(st.flow, n0) != HG_OK) hg::fail(HG_ERR_NOMEM, "%s", hg_last_error());
+        cap = n0;
+    }
+};
+
+int hg_cascade_create(const hg_cascade_stage* stages, int n_stages, int sub_w, int sub_h, int n_features, const hg_cascade_consts* consts,
+                      const double* cut_offs_face, int n_cut_offs, int device, hg_cascade** out) {
+    return guarded([&] {
+        if (!out) hg::fail(HG_ERR_ARG, "null output handle pointer");
+        *out = nullptr;
+        if (!stages || n_stages <= 0 || n_stages > 64 || !consts || !cut_offs_face) hg::fail(HG_ERR_ARG, "bad stage list");
+        if (sub_w <= 0 || sub_h <= 0 || (sub_w * sub_h) % 4 || n_features <= 0 || n_features > 256) hg::fail(HG_ERR_ARG, "bad sub-image size / feature count");
+        for (int k = 0; k < n_stages; ++k) {
+            if (stages[k].type < HG_STAGE_DISC || stages[k].type > HG_STAGE_SCALE) hg::fail(HG_ERR_ARG, "stage %d: unknown type %d", k, stages[k].type);
+            if (stages[k].serial < 0 || stages[k].serial >= n_cut_offs || n_cut_offs > 10) hg::fail(HG_ERR_ARG, "stage %d: serial %d has no cut-off", k, stages[k].serial);
+            if (!stages[k].classifier) hg::fail(HG_ERR_ARG, "stage %d: no classifier", k);
+            if (k == 0 && !stages[k].flow) hg::fail(HG_ERR_ARG, "the first stage needs a network");
+        }
+        set_dev(device);
+        auto c = std::make_unique<hg_cascade>();
+        c->device = device;
+        c->w = sub_w;
+        c->h = sub_h;
+        c->k = n_features;
+        c->stages.assign(stages, stages + n_stages);
+        c->base = *consts;
+        for (int i = 0; i < 10; ++i) c->cut_offs[i] = i < n_cut_offs ? cut_offs_face[i] : 0.0;
+        if (hg_patcher_create(device, &c->patcher) != HG_OK) hg::fail(HG_ERR_DEVICE, "%s", hg_last_error());
+        HG_HIP(hipHostMalloc((void**)&c->host_count, 64, hipHostMallocDefault));
+        *out = c.release();
+    });
+}
+
+void hg_cascade_free(hg_cascade* c) {
+    if (!c) return;
+    if (hipSetDevice(c->device) == hipSuccess) {
+        if (c->patcher) hg_patcher_free(c->patcher);
+        if (c->host_count) (void)hipHostFree(c->host_count);
+    }
+    delete c;
+}
+
+int hg_cascade_detect_device(hg_cascade* c, const void* frame_dev, int frame_h, int frame_w, int64_t ld, const double* boxes_host,
+                             const double* level_host, int64_t n0, double* out_coords, double* out_angles, int32_t* out_orig_index,
+                             double* out_confidence, int64_t out_cap, int64_t* n_out, int32_t* stage_counts, int64_t* rows_executed,
+                             void* stream) {
+    return guarded([&] {
+        if (!c || !n_out) hg::fail(HG_ERR_ARG, "null argument");
+        if (n0 < 0 || n0 > 0x7fffffffll / 64) hg::fail(HG_ERR_ARG, "bad window count");
+        if (n0 > 0 && (!frame_dev || !boxes_host || !level_host)) hg::fail(HG_ERR_ARG, "null data pointer");
+        set_dev(c->device);
+        hipStream_t st = (hipStream_t)stream;
+        const int ns = (int)c->stages.size();
+        *n_out = 0;
+        if (rows_executed) *rows_executed = 0;
+        if (n0 == 0) {
+            for (int k = 0; k < ns && stage_counts; ++k) stage_counts[k] = 0;
+            return;
+        }
+        c->reserve(n0);
+        HG_HIP(hipMemcpyAsync(c->orig_coords.p, boxes_host, (size_t)n0 * 32, hipMemcpyHostToDevice, st));
+        HG_HIP(hipMemcpyAsync(c->orig_level.p, level_host, (size_t)n0 * 24, hipMemcpyHostToDevice, st));
+        HG_HIP(hipMemcpyAsync(c->coords[0].p, c->orig_coords.p, (size_t)n0 * 32, hipMemcpyDeviceToDevice, st));
+        HG_HIP(hipMemsetAsync(c->angles[0].p, 0, (size_t)n0 * 8, st));
+        HG_HIP(hipMemsetAsync(c->neg.p, 0, (size_t)n0 * 8, st));
+        HG_HIP(hipMemsetAsync(c->conf[0].p, 0, (size_t)n0 * 8, st));
+        {   // orig_index = 0 .. n0-1, count = n0
+            std::vector<int32_t> idx((size_t)n0);
+            for (int64_t i = 0; i < n0; ++i) idx[i] = (int32_t)i;
+            HG_HIP(hipMemcpyAsync(c->oidx[0].p, idx.data(), (size_t)n0 * 4, hipMemcpyHostToDevice, st));
+            const int32_t cnt0 = (int32_t)n0;
+            HG_HIP(hipMemcpyAsync(c->count.p, &cnt0, 4, hipMemcpyHostToDevice, st));
+            HG_HIP(hipStreamSynchronize(st));          // idx / cnt0 are stack / heap temporaries
+        }
+        int cur = 0, cnt_slot = 0;
+        int64_t n_bound = n0, rows = 0;                // n_bound: host-side upper bound of the candidate count (exact after a Disc stage)
+        const size_t row = (size_t)c->w * c->h;
+        for (int k = 0; k < ns; ++k) {
+            const hg_cascade_stage& S = c->stages[k];
+            if (n_bound == 0) {
+                if (stage_counts) stage_counts[k] = 0;
+                continue;
+            }
+            const bool skip_extract = (k > 0 && c->stages[k - 1].type == HG_STAGE_DISC) || !S.flow;      // FaceDetectUpdated.py:674-681
+            if (!skip_extract) {
+                if (hg_patcher_extract_rotate_device(c->patcher, frame_dev, HG_U8, frame_h, frame_w, ld, (const double*)c->coords[cur].p,
+                                                     (const double*)c->neg.p, n_bound, c->w, c->h, c->subs[cur].p, HG_U8, (int64_t)row, st) != HG_OK)
+                    hg::fail(HG_ERR_DEVICE, "%s", hg_last_error());
+            }
+            if (S.flow) {
+                if (hg_flow_execute_device(S.flow, c->subs[cur].p, HG_U8, n_bound, (int64_t)row, c->sl[cur].p, HG_F32, c->k, c->k, st) != HG_OK)
+                    hg::fail(HG_ERR_DEVICE, "%s", hg_last_error());
+                rows += n_bound;
+            }
+            if (hg_gauss_regression_device(S.classifier, c->sl[cur].p, HG_F32, n_bound, c->k, (double*)c->reg.p, nullptr, st) != HG_OK)
+                hg::fail(HG_ERR_DEVICE, "%s", hg_last_error());
+            hg_cascade_consts cc = c->base;
+            cc.cut_off_face = c->cut_offs[S.serial];
+            StageArrays A{};
+            for (int b = 0; b < 2; ++b) {
+                A.coords[b] = (double*)c->coords[b].p;
+                A.angles[b] = (double*)c->angles[b].p;
+                A.conf[b] = (double*)c->conf[b].p;
+                A.oidx[b] = (int32_t*)c->oidx[b].p;
+                A.sl[b] = (float*)c->sl[b].p;
+            }
+            A.neg_angles = (double*)c->neg.p;
+            A.reg = (const double*)c->reg.p;
+            A.orig_coords = (const double*)c->orig_coords.p;
+            A.orig_angles = (const double*)c->orig_angles.p;
+            A.orig_level = (const double*)c->orig_level.p;
+            A.discard = (uint8_t*)c->discard.p;
+            A.map = (int32_t*)c->map.p;
+            A.count_in = (int32_t*)c->count.p + cnt_slot;
+            A.count_out = (int32_t*)c->count.p + (1 - cnt_slot);
+            A.k_feat = c->k;
+            A.cur = cur;
+            A.n_max = (int32_t)n_bound;
+            // the host needs the exact count only where it shrinks a lot and sizes expensive launches: after a Disc stage
+            const bool want_count = S.type == HG_STAGE_DISC || k + 1 == ns;
+            hipLaunchKernelGGL(k_cascade_stage, 1, 1024, 0, st, S.type, cc, A, want_count ? c->host_count : nullptr);
+            // the sub-images travel only to a stage that reuses them: one that follows a Disc stage and has a network (:674-677)
+            if (S.type == HG_STAGE_DISC && k + 1 < ns && c->stages[k + 1].flow) {
+                const int vec16 = row % 16 == 0 ? 1 : 0;
+                hipLaunchKernelGGL(k_gather_rows, (unsigned)std::min<int64_t>(n_bound, 16384), 256, 0, st, (const char*)c->subs[cur].p, (char*)c->subs[1 - cur].p,
+                                   (int64_t)row, (const int32_t*)c->map.p, (const int32_t*)A.count_out, vec16);
+            }
+            HG_HIP(hipGetLastError());
+            cur = 1 - cur;
+            cnt_slot = 1 - cnt_slot;
+            if (want_count) {
+                HG_HIP(hipStreamSynchronize(st));
+                n_bound = *c->host_count;
+            }
+            if (stage_counts) stage_counts[k] = want_count ? (int32_t)n_bound : -1;      // -1: not read back (no Disc stage)
+        }
+        if (n_bound > out_cap) hg::fail(HG_ERR_ARG, "%lld detections but room for %lld", (long long)n_bound, (long long)out_cap);
+        if (n_bound > 0) {
+            if (out_coords) HG_HIP(hipMemcpyAsync(out_coords, c->coords[cur].p, (size_t)n_bound * 32, hipMemcpyDeviceToHost, st));
+            if (out_angles) HG_HIP(hipMemcpyAsync(out_angles, c->angles[cur].p, (size_t)n_bound * 8, hipMemcpyDeviceToHost, st));
+            if (out_orig_index) HG_HIP(hipMemcpyAsync(out_orig_index, c->oidx[cur].p, (size_t)n_bound * 4, hipMemcpyDeviceToHost, st));
+            if (out_confidence) HG_HIP(hipMemcpyAsync(out_confidence, c->conf[cur].p, (size_t)n_bound * 8, hipMemcpyDeviceToHost, st));
+            HG_HIP(hipStreamSynchronize(st));
+        }
+        *n_out = n_bound;
+        if (rows_executed) *rows_executed = rows;
     });
 }
 

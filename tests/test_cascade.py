@@ -94,7 +94,11 @@ def test_device_cascade_matches_restated_loop(native_lib, nets):
     def regress(k, sl):
         return stages[k].classifier.regression(np.ascontiguousarray(sl[:, :stages[k].classifier.input_dim]))
     ref = CR.run_cascade([s.name for s in stages], [s.flow is not None for s in stages], boxes, level, pipe, extract, execute, regress)
-    assert got["counts"] == ref["counts"] and got["rows_executed"] == ref["rows_executed"], (got["counts"], ref["counts"])
+    # survivor counts are read back after Disc stages only (-1 elsewhere: the count stays on the device)
+    known = [i for i, c in enumerate(got["counts"]) if c >= 0]
+    assert [stages[i].type for i in known] == ["Disc"] * len(known) and len(known) == 5
+    assert [got["counts"][i] for i in known] == [ref["counts"][i] for i in known], (got["counts"], ref["counts"])
+    assert got["rows_executed"] >= ref["rows_executed"]        # launches between two Disc stages are sized by the last count read
     assert 0 < got["counts"][-1] < len(boxes) and got["counts"][0] < len(boxes)
     assert np.array_equal(got["orig_index"], ref["orig_index"])
     assert np.array_equal(got["coords"], ref["coords"]) and np.array_equal(got["angles"], ref["angles"])
@@ -162,7 +166,8 @@ def test_config3_full_pyramid_1080p(native_lib, nets):
     want = CR.run_cascade([s.name for s in stages], [s.flow is not None for s in stages], boxes, level, pipe, extract, execute, regress)
     # the device loop runs a stage's survivors at another batch size than the host loop's calls, and U11L-128 features depend on N
     # in the last bits (tests/test_gpu_host_path.py::test_batch_size_dependence_is_bounded): decisions agree, numbers to 1e-5
-    assert got["counts"] == want["counts"], (got["counts"], want["counts"])
+    known = [i for i, c in enumerate(got["counts"]) if c >= 0]
+    assert [got["counts"][i] for i in known] == [want["counts"][i] for i in known], (got["counts"], want["counts"])
     assert np.array_equal(got["orig_index"], want["orig_index"])
     assert np.allclose(got["coords"], want["coords"], rtol=0, atol=1e-3) and np.allclose(got["angles"], want["angles"], rtol=0, atol=1e-3)
     dc.close()
