@@ -245,6 +245,17 @@ int hg_cascade_detect_device(hg_cascade* c, const void* frame_dev, int frame_h, 
 int hg_sfa_train_layer(const void* x, int x_on_host, int x_dtype, int64_t n, int64_t ldx, const int32_t* conn_host,
                        int32_t n_nodes, int32_t d, int device, double* evals_host, double* evecs_host,
                        double* mean_host, double* timings_ms);
+/* The PCA / whitening step of a node (mdp.nodes.PCANode / WhiteningNode train + stop_training): same statistics kernel, then the
+ * eigen-decomposition of Cov(x) itself (the same solver on (Cov, I)): evals ascending, orthonormal eigenvectors. */
+int hg_pca_train_layer(const void* x, int x_on_host, int x_dtype, int64_t n, int64_t ldx, const int32_t* conn_host,
+                       int32_t n_nodes, int32_t d, int device, double* evals_host, double* evecs_host,
+                       double* mean_host, double* timings_ms);
+/* What a trained step passes on during training, in float64 like MDP: out[t, node * width + f * p + j] =
+ * func_f(((x[t, conn[node]] - mean[node]) W[node])_j), width = max(1, n_funcs) * p; n_funcs = 0: the affine map alone.
+ * func_kinds: 0 identity, 1 |z|^e, 2 sgn(z)|z|^e.  x_dev / out_dev: device; conn / mean / W (n_nodes, d, p row-major): host. */
+int hg_train_apply_device(const void* x_dev, int x_dtype, int64_t n, int64_t ldx, const int32_t* conn_host, int32_t n_nodes,
+                          int32_t d, const double* mean_host, const double* w_host, int32_t p, int32_t n_funcs,
+                          const int32_t* func_kinds, const double* func_expos, double* out_dev, int64_t ldo, int device);
 
 #ifdef __cplusplus
 }

@@ -95,6 +95,8 @@ def lib():
         "hg_cascade_free": (None, [vp]),
         "hg_cascade_detect_device": (C.c_int, [vp, vp, i32, i32, i64, vp, vp, i64, vp, vp, vp, vp, i64, C.POINTER(i64), vp, C.POINTER(i64), vp]),
         "hg_sfa_train_layer": (C.c_int, [vp, i32, i32, i64, i64, vp, C.c_int32, C.c_int32, i32, vp, vp, vp, vp]),
+        "hg_pca_train_layer": (C.c_int, [vp, i32, i32, i64, i64, vp, C.c_int32, C.c_int32, i32, vp, vp, vp, vp]),
+        "hg_train_apply_device": (C.c_int, [vp, i32, i64, i64, vp, C.c_int32, C.c_int32, vp, vp, C.c_int32, C.c_int32, vp, vp, vp, i64, i32]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(L, name)
@@ -112,7 +114,7 @@ EXPORTED_SYMBOLS = (
     "hg_gauss_regression", "hg_patcher_create", "hg_patcher_free", "hg_patcher_extract_device",
     "hg_patcher_extract", "hg_patcher_extract_rotate_device", "hg_patcher_extract_rotate", "hg_cascade_update_device",
     "hg_cascade_compact_device", "hg_gather_rows_device", "hg_cascade_create", "hg_cascade_free", "hg_cascade_detect_device",
-    "hg_sfa_train_layer",
+    "hg_sfa_train_layer", "hg_pca_train_layer", "hg_train_apply_device",
 )
 
 _EXC = {HG_ERR_ARG: ValueError, HG_ERR_FORMAT: ValueError, HG_ERR_DIM: ValueError,

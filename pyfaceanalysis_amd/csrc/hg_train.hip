@@ -33,46 +33,49 @@ __global__ void __launch_bounds__(256) k_sfa_stats(const XT* __restrict__ x, int
     const int64_t t0 = split * per, t1 = min(n, t0 + per);
     const int32_t* cols = conn + (size_t)node * d;
     const int dd = d * d;
-    // each thread owns entries e = tid, tid + 256, ... of the d x d matrices (<= 16 for d = 64)
-    double sxx[16], sdd[16], sx = 0.0;
+    // each thread owns entries e = e_base + tid, + 256, ... of the d x d matrices: 16 per pass over the samples, so nodes of up
+    // to 64 inputs take one pass and wider ones (up to 128: the upper layers of an 11-layer net) up to four
+    double* out = partial + ((size_t)split * n_nodes + node) * (size_t)(d + 2 * dd);
+    for (int e_base = 0; e_base < dd; e_base += 16 * 256) {
+        double sxx[16], sdd[16], sx = 0.0;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) sxx[k] = sdd[k] = 0.0;
-    for (int64_t tb = t0; tb < t1; tb += kTS) {
-        const int m = (int)min<int64_t>(kTS, t1 - tb);
-        const int mm = (tb + m < n) ? m + 1 : m;            // one sample ahead for the last difference of the chunk
-        __syncthreads();
-        for (int idx = tid; idx < mm * d; idx += 256) {
-            const int tt = idx / d, c = idx - tt * d;
-            xs[idx] = (double)x[(tb + tt) * ldx + cols[c]];
+        for (int k = 0; k < 16; ++k) sxx[k] = sdd[k] = 0.0;
+        for (int64_t tb = t0; tb < t1; tb += kTS) {
+            const int m = (int)min<int64_t>(kTS, t1 - tb);
+            const int mm = (tb + m < n) ? m + 1 : m;            // one sample ahead for the last difference of the chunk
+            __syncthreads();
+            for (int idx = tid; idx < mm * d; idx += 256) {
+                const int tt = idx / d, c = idx - tt * d;
+                xs[idx] = (double)x[(tb + tt) * ldx + cols[c]];
+            }
+            __syncthreads();
+            const int nd = mm - 1;   // differences x[t+1] - x[t] that START in this chunk (the last sample overall starts none)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int e = e_base + tid + k * 256;
+                if (e < dd) {
+                    const int i = e / d, j = e - i * d;
+                    double a = sxx[k], b = sdd[k];
+                    for (int tt = 0; tt < m; ++tt) a += xs[tt * d + i] * xs[tt * d + j];
+                    for (int tt = 0; tt < nd; ++tt) {
+                        const double di = xs[(tt + 1) * d + i] - xs[tt * d + i], dj = xs[(tt + 1) * d + j] - xs[tt * d + j];
+                        b += di * dj;
+                    }
+                    sxx[k] = a;
+                    sdd[k] = b;
+                }
+            }
+            if (e_base == 0 && tid < d)
+                for (int tt = 0; tt < m; ++tt) sx += xs[tt * d + tid];
         }
-        __syncthreads();
-        const int nd = mm - 1;   // differences x[t+1] - x[t] that START in this chunk (the last sample overall starts none)
+        if (e_base == 0 && tid < d) out[tid] = sx;
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            const int e = tid + k * 256;
+            const int e = e_base + tid + k * 256;
             if (e < dd) {
-                const int i = e / d, j = e - i * d;
-                double a = sxx[k], b = sdd[k];
-                for (int tt = 0; tt < m; ++tt) a += xs[tt * d + i] * xs[tt * d + j];
-                for (int tt = 0; tt < nd; ++tt) {
-                    const double di = xs[(tt + 1) * d + i] - xs[tt * d + i], dj = xs[(tt + 1) * d + j] - xs[tt * d + j];
-                    b += di * dj;
-                }
-                sxx[k] = a;
-                sdd[k] = b;
+                out[d + e] = sxx[k];
+                out[d + dd + e] = sdd[k];
             }
-        }
-        if (tid < d)
-            for (int tt = 0; tt < m; ++tt) sx += xs[tt * d + tid];
-    }
-    double* out = partial + ((size_t)split * n_nodes + node) * (size_t)(d + 2 * dd);
-    if (tid < d) out[tid] = sx;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int e = tid + k * 256;
-        if (e < dd) {
-            out[d + e] = sxx[k];
-            out[d + dd + e] = sdd[k];
         }
     }
 }
@@ -349,14 +352,51 @@ int guarded(F&& fn) {
     }
 }
 
-}  // namespace
+__global__ void k_fill_identity(double* __restrict__ m, int d, int64_t total) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int r = (int)(e % ((int64_t)d * d));
+    m[e] = (r / d == r % d) ? 1.0 : 0.0;
+}
 
-extern "C" int hg_sfa_train_layer(const void* x_in, int x_on_host, int x_dtype, int64_t n, int64_t ldx, const int32_t* conn_host, int32_t n_nodes,
-                                  int32_t d, int device, double* evals_host, double* evecs_host, double* mean_host,
-                                  double* timings_ms) {
+// out[t, node * width + f * p + j] = func_f(z_j),  z = (x[t, conn[node]] - mean[node]) W[node]   — float64 throughout: the data a
+// layer passes to the statistics of the next one during training (MDP trains in float64).  One thread per (row, node, j).
+template <typename XT>
+__global__ void __launch_bounds__(256) k_train_apply(const XT* __restrict__ x, int64_t ldx, int64_t n, const int32_t* __restrict__ conn, int d,
+                                                      int n_nodes, const double* __restrict__ mean, const double* __restrict__ W, int p, int nf,
+                                                      const int* __restrict__ kinds, const double* __restrict__ expos, double* __restrict__ out,
+                                                      int64_t ldo) {
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = n * n_nodes * p;
+    if (id >= total) return;
+    const int j = (int)(id % p);
+    const int node = (int)((id / p) % n_nodes);
+    const int64_t t = id / ((int64_t)p * n_nodes);
+    const int32_t* cols = conn + (size_t)node * d;
+    const double* mu = mean + (size_t)node * d;
+    const double* Wn = W + (size_t)node * d * p;
+    const XT* xr = x + t * ldx;
+    double z = 0.0;
+    for (int i = 0; i < d; ++i) z = __fma_rn((double)xr[cols[i]] - mu[i], Wn[(size_t)i * p + j], z);
+    double* o = out + t * ldo + (size_t)node * (nf > 0 ? nf : 1) * p;
+    if (nf <= 0) {
+        o[j] = z;
+        return;
+    }
+    for (int f = 0; f < nf; ++f) {
+        double v = z;
+        if (kinds[f] == (int)hg::E_ABS_POW) v = pow(fabs(z), expos[f]);
+        else if (kinds[f] == (int)hg::E_SIGNED_POW) v = copysign(pow(fabs(z), expos[f]), z);
+        o[(size_t)f * p + j] = v;
+    }
+}
+
+int train_layer_impl(const void* x_in, int x_on_host, int x_dtype, int64_t n, int64_t ldx, const int32_t* conn_host, int32_t n_nodes,
+                     int32_t d, int mode, int device, double* evals_host, double* evecs_host, double* mean_host, double* timings_ms) {
     return guarded([&] {
+        if (mode != 0 && mode != 1) hg::fail(HG_ERR_ARG, "mode must be 0 (SFA) or 1 (PCA)");
         if (!x_in || !conn_host || !evals_host || !evecs_host || !mean_host) hg::fail(HG_ERR_ARG, "null pointer");
-        if (n < 3 || n_nodes < 1 || d < 1 || d > 64) hg::fail(HG_ERR_ARG, "need n >= 3 samples, 1..64 inputs per node");
+        if (n < 3 || n_nodes < 1 || d < 1 || d > 128) hg::fail(HG_ERR_ARG, "need n >= 3 samples, 1..128 inputs per node");
         if (x_dtype != HG_U8 && x_dtype != HG_F32 && x_dtype != HG_F64) hg::fail(HG_ERR_ARG, "bad dtype");
         int count = 0;
         if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
@@ -442,6 +482,10 @@ extern "C" int hg_sfa_train_layer(const void* x_in, int x_on_host, int x_dtype, 
                 if (l2 > 64 * 1024) HG_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2));
                 hipLaunchKernelGGL(fn, g16, 512, l2, nullptr, (const double*)x_dev, ldx, n, uc, co, li, d, n_nodes, n_chunks, n_splits, rs, pp);
             }
+        } else if (lds > 64 * 1024 && (hipFuncSetAttribute((const void*)k_sfa_stats<uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                                       hipFuncSetAttribute((const void*)k_sfa_stats<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                                       hipFuncSetAttribute((const void*)k_sfa_stats<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)) {
+            hg::fail(HG_ERR_DEVICE, "cannot raise the LDS limit of the statistics kernel");
         } else if (x_dtype == HG_U8)
             hipLaunchKernelGGL(k_sfa_stats<uint8_t>, grid, 256, lds, nullptr, (const uint8_t*)x_dev, ldx, n, (const int32_t*)conn.p, d, n_nodes,
                                n_splits, (double*)partial.p);
@@ -456,6 +500,11 @@ extern "C" int hg_sfa_train_layer(const void* x_in, int x_on_host, int x_dtype, 
         HG_HIP(hipGetLastError());
         // Solver: nodes of <= 16 inputs go to the hand-written one-wave-per-node Jacobi kernel; wider nodes (or
         // HIGSFA_SYGVJ=1 / HIGSFA_SYGVD=1) to rocSOLVER's batched Jacobi / divide-and-conquer routines.
+        if (mode == 1) {      // PCA: eigen-decomposition of the covariance itself = the same solver on (Cov, I)
+            HG_HIP(hipMemcpyAsync(A.p, B.p, (size_t)n_nodes * dd * 8, hipMemcpyDeviceToDevice, nullptr));
+            const int64_t total = (int64_t)n_nodes * dd;
+            hipLaunchKernelGGL(k_fill_identity, (unsigned)((total + 255) / 256), 256, 0, nullptr, (double*)B.p, d, total);
+        }
         rocblas_status rs = rocblas_status_success;
         hg::DevBuf Wv;     // eigenvectors of the hand-written solver (rocSOLVER overwrites A instead)
         const bool own_solver = d <= 16 && !getenv("HIGSFA_SYGVD") && !getenv("HIGSFA_SYGVJ");
@@ -498,3 +547,62 @@ extern "C" int hg_sfa_train_layer(const void* x_in, int x_on_host, int x_dtype, 
         (void)hipEventDestroy(e2);
     });
 }
+
+}  // namespace
+
+extern "C" {
+
+int hg_sfa_train_layer(const void* x, int x_on_host, int x_dtype, int64_t n, int64_t ldx, const int32_t* conn_host, int32_t n_nodes, int32_t d,
+                       int device, double* evals_host, double* evecs_host, double* mean_host, double* timings_ms) {
+    return train_layer_impl(x, x_on_host, x_dtype, n, ldx, conn_host, n_nodes, d, 0, device, evals_host, evecs_host, mean_host, timings_ms);
+}
+
+int hg_pca_train_layer(const void* x, int x_on_host, int x_dtype, int64_t n, int64_t ldx, const int32_t* conn_host, int32_t n_nodes, int32_t d,
+                       int device, double* evals_host, double* evecs_host, double* mean_host, double* timings_ms) {
+    return train_layer_impl(x, x_on_host, x_dtype, n, ldx, conn_host, n_nodes, d, 1, device, evals_host, evecs_host, mean_host, timings_ms);
+}
+
+int hg_train_apply_device(const void* x_dev, int x_dtype, int64_t n, int64_t ldx, const int32_t* conn_host, int32_t n_nodes, int32_t d,
+                          const double* mean_host, const double* w_host, int32_t p, int32_t n_funcs, const int32_t* func_kinds,
+                          const double* func_expos, double* out_dev, int64_t ldo, int device) {
+    return guarded([&] {
+        if (!x_dev || !conn_host || !mean_host || !w_host || !out_dev) hg::fail(HG_ERR_ARG, "null pointer");
+        if (n < 1 || n_nodes < 1 || d < 1 || p < 1 || n_funcs < 0 || n_funcs > 8) hg::fail(HG_ERR_ARG, "bad sizes");
+        if (x_dtype != HG_U8 && x_dtype != HG_F32 && x_dtype != HG_F64) hg::fail(HG_ERR_ARG, "bad dtype");
+        if (ldo < (int64_t)n_nodes * std::max(1, n_funcs) * p) hg::fail(HG_ERR_ARG, "ldo too small");
+        for (int f = 0; f < n_funcs; ++f)
+            if (!func_kinds || func_kinds[f] < 0 || func_kinds[f] > (int)hg::E_SIGNED_POW || (func_kinds[f] != 0 && !func_expos))
+                hg::fail(HG_ERR_ARG, "only element-wise expansion functions");
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+            hg::fail(HG_ERR_DEVICE, "no HIP device available (this library has no CPU execution path)");
+        if (device < 0 || device >= count) hg::fail(HG_ERR_DEVICE, "device %d out of range", device);
+        HG_HIP(hipSetDevice(device));
+        for (int64_t i = 0; i < (int64_t)n_nodes * d; ++i)
+            if (conn_host[i] < 0 || conn_host[i] >= ldx) hg::fail(HG_ERR_ARG, "connection %d out of range", conn_host[i]);
+        hg::DevBuf conn, mean, W, kinds, expos;
+        conn.upload(conn_host, (size_t)n_nodes * d * 4);
+        mean.upload(mean_host, (size_t)n_nodes * d * 8);
+        W.upload(w_host, (size_t)n_nodes * d * p * 8);
+        if (n_funcs) {
+            kinds.upload(func_kinds, (size_t)n_funcs * 4);
+            std::vector<double> ex(n_funcs, 1.0);
+            for (int f = 0; f < n_funcs; ++f)
+                if (func_expos) ex[f] = func_expos[f];
+            expos.upload(ex.data(), (size_t)n_funcs * 8);
+        }
+        const int64_t total = n * n_nodes * p;
+        if ((total + 255) / 256 > 0x7fffffffll) hg::fail(HG_ERR_ARG, "too much work for one launch");
+        const unsigned grid = (unsigned)((total + 255) / 256);
+#define HG_APPLY(XT) hipLaunchKernelGGL(k_train_apply<XT>, grid, 256, 0, nullptr, (const XT*)x_dev, ldx, n, (const int32_t*)conn.p, d, n_nodes, \
+                                        (const double*)mean.p, (const double*)W.p, p, n_funcs, (const int*)kinds.p, (const double*)expos.p, out_dev, ldo)
+        if (x_dtype == HG_U8) HG_APPLY(uint8_t);
+        else if (x_dtype == HG_F32) HG_APPLY(float);
+        else HG_APPLY(double);
+#undef HG_APPLY
+        HG_HIP(hipGetLastError());
+        HG_HIP(hipDeviceSynchronize());
+    });
+}
+
+}  // extern "C"

@@ -133,7 +133,7 @@ def _train_sfa(e, s):
 
 
 def train_hierarchy(side, f0, layer_dims, n_train=1500, seed=WEIGHT_SEED, node_kind="pca_exp_sfa",
-                    expo=0.8, layout="flownode", verbose=False):
+                    expo=0.8, layout="flownode", verbose=False, device=None):
     """Build + train the hierarchy.  Returns the list of top-level nodes
     ``[Switchboard, Layer, Switchboard, Layer, ...]`` (a ``Flow.flow`` list).
 
@@ -142,7 +142,15 @@ def train_hierarchy(side, f0, layer_dims, n_train=1500, seed=WEIGHT_SEED, node_k
     layout    : "flownode"  -> Layer([FlowNode([PCA, Exp, SFA]), ...])
                 "separate"  -> Layer([PCA...]), Layer([Exp...]), Layer([SFA...])  (how
                                cuicuilco's network builder stacks them)
+    device    : None -> numpy on the host (below); a HIP device ordinal -> statistics, eigen-solves and the
+                layer-to-layer passes on that GPU (pyfaceanalysis_amd.train.train_hierarchy_device, "pca_exp_sfa" only)
     """
+    if device is not None:
+        if node_kind != "pca_exp_sfa":
+            raise ValueError("device training covers node_kind 'pca_exp_sfa'")
+        from .train import train_hierarchy_device
+        return train_hierarchy_device(side, f0, layer_dims, n_train=n_train, seed=seed, expo=expo, layout=layout, device=device,
+                                      verbose=verbose)
     x = make_training_sequence(n_train, side, seed)                    # (T, side*side)
     grid = None
     flow = []
@@ -231,12 +239,12 @@ def train_hierarchy(side, f0, layer_dims, n_train=1500, seed=WEIGHT_SEED, node_k
 
 
 def build_preset(name="U11L-128", n_train=None, seed=WEIGHT_SEED, node_kind="pca_exp_sfa",
-                 layout="flownode", verbose=False):
+                 layout="flownode", verbose=False, device=None):
     side, f0, dims = PRESETS[name]
     if n_train is None:
         n_train = 1500 if side >= 64 else 600
     return train_hierarchy(side, f0, dims, n_train=n_train, seed=seed, node_kind=node_kind,
-                           layout=layout, verbose=verbose)
+                           layout=layout, verbose=verbose, device=device)
 
 
 def preset_input_side(name):

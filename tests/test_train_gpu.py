@@ -55,3 +55,98 @@ def test_sfa_train_layer_other_widths(native_lib, field, stride, dt):
         assert np.abs(evals[k] / w - 1).max() < 1e-5
         g = np.abs(v.T @ B @ evecs[k])
         assert np.abs(np.diag(g) - 1).max() < 1e-5
+
+
+def _net_weights(flow):
+    from pyfaceanalysis_amd import nodes as N
+    out = []
+    for nd in flow:
+        if isinstance(nd, N.Layer):
+            for fn in nd.nodes:
+                pca, _exp, sfa = fn.flow
+                out.append((pca.avg, pca.v, sfa.avg, sfa.sf))
+    return out
+
+
+@pytest.mark.parametrize("preset", ["T5L-16", "T3L-8"])
+def test_hierarchy_trained_on_gpu_equals_numpy(native_lib, preset):
+    """synth.train_hierarchy(device=0): per-layer statistics, PCA and SFA eigen-solves and the float64 layer-to-layer passes on
+    the GPU, against the numpy trainer on the same seeded sequence: same whitening matrices and slow-feature vectors after the
+    shared sign convention, same network outputs on fresh inputs (float64, 1e-8 relative)."""
+    from oracle import mdp_restate
+    from pyfaceanalysis_amd import synth
+    host = synth.build_preset(preset)
+    dev = synth.build_preset(preset, device=0)
+    assert [type(a).__name__ for a in host] == [type(b).__name__ for b in dev]
+    # whitening vectors up to the sign of a column (the shared convention "largest entry positive" can tie between two entries;
+    # a flipped component flips one row of the node's SFA matrix and nothing downstream)
+    # Beyond the first layer a flipped SFA output column upstream flips means and rows downstream as well (outputs unchanged
+    # up to the sign of a column), so the matrices are compared on the first layer and the networks on their outputs.
+    worst = 0.0
+    n_first = len(host[1].nodes)
+    for (a1, v1, m1, s1), (a2, v2, m2, s2) in list(zip(_net_weights(host), _net_weights(dev)))[:n_first]:
+        assert v1.shape == v2.shape and s1.shape == s2.shape
+        worst = max(worst, float(np.abs(a1 - a2).max() / np.abs(a1).max()))
+        col = np.minimum(np.abs(v1 - v2).max(axis=0), np.abs(v1 + v2).max(axis=0)) / np.abs(v1).max()
+        worst = max(worst, float(col.max()))
+    x = synth.make_subimages(50, synth.preset_input_side(preset), seed=99, dtype=np.float64)
+    ya, yb = mdp_restate.execute_flow(host, x), mdp_restate.execute_flow(dev, x)
+    err = float(np.minimum(np.abs(ya - yb).max(axis=0), np.abs(ya + yb).max(axis=0)).max() / np.abs(ya).max())
+    print("%s: worst whitening-matrix difference %.2e, output difference %.2e" % (preset, worst, err))
+    assert err <= 1e-8 and worst <= 1e-7
+
+
+def test_wide_nodes_and_config5_size(native_lib):
+    """(1) nodes wider than 64 inputs (the upper layers of the 11-layer nets have 70 and 120): PCA and SFA steps against
+    numpy; (2) BASELINE.json configs[4] at its real size — 100 000 patches of 128x128 (uint8, 1.64 GB resident), 1024 nodes of
+    16 inputs: statistics + generalized eigen-solve, eigenvalues / eigenvectors of a sample of nodes against scipy to 1e-5."""
+    import torch
+    from pyfaceanalysis_amd import nodes as N, synth
+    from pyfaceanalysis_amd.train import pca_train_layer, sfa_train_layer
+    rng = np.random.default_rng(3)
+    T, d = 900, 120
+    base = rng.normal(size=(T, 40)).cumsum(axis=0) * 0.05 + rng.normal(size=(T, 40))
+    xh = np.concatenate([base @ rng.normal(size=(40, d)) + 0.1 * rng.normal(size=(T, d)) for _ in range(3)], axis=1)      # 3 nodes x 120
+    conn = np.arange(3 * d, dtype=np.int32).reshape(3, d)
+    xd = torch.from_numpy(xh).cuda()
+    lam, vec, mu, _ = pca_train_layer(xd.data_ptr(), np.float64, T, xh.shape[1], conn)
+    ev, W, mu2, _ = sfa_train_layer(xd.data_ptr(), conn, x_dtype=np.float64, n=T, ldx=xh.shape[1])
+    for k in range(3):
+        xk = xh[:, conn[k]]
+        B = np.cov(xk.T)
+        w = np.linalg.eigvalsh(B)
+        assert np.allclose(mu[k], xk.mean(axis=0), rtol=1e-11) and np.abs(lam[k] / w - 1).max() < 1e-8
+        assert np.abs(vec[k].T @ vec[k] - np.eye(d)).max() < 1e-9 and np.abs(vec[k].T @ B @ vec[k] - np.diag(lam[k])).max() < 1e-8 * w.max()
+        dx = xk[1:] - xk[:-1]
+        A = dx.T @ dx / (T - 1)
+        w2, v2 = scipy.linalg.eigh(A, B)
+        assert np.abs(ev[k] / w2 - 1).max() < 1e-6
+        assert np.abs(np.abs(np.diag(v2.T @ B @ W[k])) - 1).max() < 1e-6
+    del xd
+    # configs[4]
+    n, side = 100_000, 128
+    tex = torch.from_numpy(np.rint(synth._box3(rng.integers(0, 256, (side + 600, side + 600), dtype=np.uint8))).astype(np.uint8)).cuda()
+    t = torch.arange(n, device="cuda", dtype=torch.float64)
+    px = torch.round((0.5 + 0.5 * torch.sin(0.0021 * t)) * 599).long()
+    py = torch.round((0.5 + 0.5 * torch.sin(0.00153 * t + 1.0)) * 599).long()
+    x = torch.empty((n, side * side), dtype=torch.uint8, device="cuda")
+    idx = torch.arange(side, device="cuda")
+    for i0 in range(0, n, 5000):                     # a window gliding over the texture: consecutive patches overlap
+        sl = slice(i0, min(n, i0 + 5000))
+        rows = (py[sl, None] + idx[None, :])[:, :, None]
+        cols = (px[sl, None] + idx[None, :])[:, None, :]
+        x[sl] = tex[rows, cols].reshape(-1, side * side)
+    sb = N.Rectangular2dSwitchboard((side, side), (4, 4), (4, 4), 1)
+    conn = sb.connections.reshape(-1, 16)
+    ev, W, mu, tms = sfa_train_layer(x.data_ptr(), conn, x_dtype=np.uint8, n=n, ldx=side * side)
+    print("configs[4]: 100k x 128x128, 1024 nodes: statistics %.2f ms, eigen-solve %.2f ms" % tms)
+    assert ev.shape == (1024, 16) and np.all(np.diff(ev, axis=1) >= 0)
+    for k in (0, 517, 1023):
+        xk = x[:, torch.from_numpy(conn[k].astype(np.int64)).cuda()].double().cpu().numpy()
+        B = np.cov(xk.T)
+        dx = xk[1:] - xk[:-1]
+        A = dx.T @ dx / (n - 1)
+        w, v = scipy.linalg.eigh(A, B)
+        assert np.allclose(mu[k], xk.mean(axis=0), rtol=1e-11)
+        assert np.abs(ev[k] / w - 1).max() < 1e-5
+        assert np.abs(np.abs(np.diag(v.T @ B @ W[k])) - 1).max() < 1e-5
