@@ -47,6 +47,27 @@ def linear_net(seed=0):
     return [sb0, l0, sb1, l1]
 
 
+def linear_u11l_96(seed=0):
+    """The shape of the reference's age network: 'linearPCANetworkU11L' fed 96x96 sub-images
+    (Pipelines/Pipeline_experimental.txt:4,64; call site face_analysis.py:1257): 96 = 3 * 32, so 3x3 fields give 32x32
+    first-layer nodes and ten pair merges reach one node — 11 layers, every node linear (PCA then SFA, which fold into one
+    affine map).  Random weights (the trained flow is not shipped); a side that is not 4 * 2^k and 9-pixel fields."""
+    rng = np.random.default_rng(seed)
+    dims = [6, 9, 12, 16, 20, 24, 28, 32, 36, 40, 30]
+    flow, c, w, h = [], 1, 96, 96
+    for li, s_out in enumerate(dims):
+        field = (3, 3) if li == 0 else ((2, 1) if li % 2 == 1 else (1, 2))
+        sb = N.Rectangular2dSwitchboard((w, h), field, field, c)
+        d_in = sb.out_channel_dim
+        p = min(d_in, s_out + 2)
+        layer = N.Layer([N.FlowNode([rand_pca(rng, d_in, p), rand_sfa(rng, p, s_out)]) for _ in range(sb.output_channels)])
+        flow += [sb, layer]
+        w, h = sb.out_channels_xy
+        c = s_out
+    assert (w, h) == (1, 1) and len(flow) == 22
+    return flow
+
+
 def product_net(seed=0):
     """Expansions with cross-column products (QT, pair products), HeadNode, CutoffNode: generic plan."""
     rng = np.random.default_rng(seed)

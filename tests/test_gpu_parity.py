@@ -239,6 +239,25 @@ def test_u11l_64_matches_oracle(native_lib, nets):
     flow.close()
 
 
+def test_linear_11_layer_net_on_96x96(native_lib):
+    """The age pipeline's shape (Pipelines/Pipeline_experimental.txt:4,64; face_analysis.py:1257): a linear 11-layer network
+    on 96x96 sub-images — a side that is not 4 * 2^k, 3x3 receptive fields, affine-only nodes — through the fused plan; the
+    caller reads 4-5 features of it."""
+    nodes = helpers.linear_u11l_96(2)
+    flow = Flow(nodes)
+    inf = flow.info()
+    assert inf.plan_kind == _capi.HG_PLAN_FUSED and inf.input_dim == 96 * 96 and inf.n_top_nodes == 22
+    x = synth.make_subimages(40, 96, dtype=np.float64)
+    ref = oracle.execute_flow(nodes, x)
+    assert rel_err(flow.execute(x), ref) <= TOL
+    assert np.array_equal(flow.execute(x.astype(np.uint8), n_cols=5), flow.execute(x, n_cols=5))
+    assert rel_err(flow.execute(x[:1]), ref[:1]) <= TOL          # one face at a time is how the reference calls it (:1257)
+    gen = Flow(nodes, force_generic=True)
+    assert rel_err(gen.execute(x), ref) <= TOL
+    flow.close()
+    gen.close()
+
+
 def test_input_dtypes_layouts_and_edges(native_lib, nets):
     nodes = nets("T5L-16")
     flow = Flow(nodes)
