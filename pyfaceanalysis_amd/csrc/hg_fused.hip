@@ -46,6 +46,8 @@ struct FusedOptions {
     // (tools/small_batch2.py): 5-10 % of a call up to N = 128, a loss from N = 340 (one workgroup per node and slice cannot
     // match the per-layer kernels' throughput), so the default stops at 8 tiles.
     int chain_max_tiles = 8;
+    int splitm_max_nodes = 4;     // experiments: HIGSFA_SPLITM_MAX
+    int shape_variant = 0;        // experiments: HIGSFA_SHAPES
     static FusedOptions from_env() {
         FusedOptions o;
         o.no_rem4 = getenv("HIGSFA_NO_REM4") != nullptr;
@@ -57,6 +59,8 @@ struct FusedOptions {
         if (const char* e = getenv("HIGSFA_STAMP")) o.stamp_stage = atoi(e);
         if (const char* e = getenv("HIGSFA_IG_SHAPE")) sscanf(e, "%d,%d", &o.ig_w, &o.ig_t);
         if (const char* e = getenv("HIGSFA_CHAIN_MAX_TILES")) o.chain_max_tiles = std::max(0, atoi(e));
+        if (const char* e = getenv("HIGSFA_SPLITM_MAX")) o.splitm_max_nodes = atoi(e);
+        if (const char* e = getenv("HIGSFA_SHAPES")) o.shape_variant = atoi(e);
         return o;
     }
 };
@@ -1332,7 +1336,7 @@ public:
                     hipLaunchKernelGGL(fn, (unsigned)blocks, T == 4 ? 512 : 256, lds_bytes, st, P);
                 }
             } else {
-                if (s.kind == 0 && s.n_nodes <= 4 && s.mt1 * s.nf <= 8 && (int64_t)s.n_nodes * n_tiles <= 8192) {
+                if (s.kind == 0 && s.n_nodes <= opt_.splitm_max_nodes && s.mt1 * s.nf <= 8 && (int64_t)s.n_nodes * n_tiles <= 8192) {
                     // top of the hierarchy: split the m-tiles of a node over the waves of a small workgroup
                     const int T = n_tiles >= 2 * 256 / std::max(1, s.n_nodes) ? 2 : 1;
                     const int groups = (n_tiles + T - 1) / T;
@@ -1358,9 +1362,14 @@ public:
                 // waves x tiles per workgroup: the largest shape that still yields >= 512 workgroups
                 // waves x tiles per workgroup: the largest shape that still gives every CU a
                 // workgroup; never fewer than 4 waves to copy a node's weights unless the batch is tiny
-                static const int shapes[][2] = {{8, 2}, {4, 2}, {4, 1}};
+                static const int shapes0[][2] = {{8, 2}, {4, 2}, {4, 1}, {0, 0}};
+                static const int shapes1[][2] = {{8, 2}, {8, 1}, {4, 1}, {0, 0}};
+                static const int shapes2[][2] = {{8, 2}, {8, 1}, {4, 2}, {4, 1}};
+                const int (*shapes)[2] = opt_.shape_variant == 1 ? shapes1 : opt_.shape_variant == 2 ? shapes2 : shapes0;
                 int nw = 4, T = 1;
-                for (auto& sh : shapes) {
+                for (int si2 = 0; si2 < 4; ++si2) {
+                    const int* sh = shapes[si2];
+                    if (!sh[0]) break;
                     int64_t tg = (n_tiles + sh[0] * sh[1] - 1) / (sh[0] * sh[1]);
                     if (sh[0] * sh[1] <= n_tiles && tg * n_groups >= 256) {
                         nw = sh[0];
