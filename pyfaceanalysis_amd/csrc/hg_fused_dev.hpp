@@ -132,12 +132,19 @@ __device__ __forceinline__ void gemm_block(WP wp, const f32x4 (&b)[T], f32x4 (&a
 // padding multiplications of those tiles gone.
 #define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 0, 0, 0)
 
+// Sum over the four lane groups (rows of 16 lanes) on the vector ALU: v_permlane16_swap pairs rows 0/1 and 2/3,
+// v_permlane32_swap the two halves — (r0 + r1) + (r2 + r3) in every row, the same association as the LDS-crossbar shuffles
+// (__shfl_xor 16, then 32) this replaces, without their ~100-cycle round trips.
+__device__ __forceinline__ float sum_lane_groups(float v) {
+    const auto p = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    const float t = __uint_as_float(p[0]) + __uint_as_float(p[1]);
+    const auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+
 __device__ __forceinline__ f32x4 rem4_rows(f32x4 d, int g) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        d[i] += __shfl_xor(d[i], 16);
-        d[i] += __shfl_xor(d[i], 32);
-    }
+    for (int i = 0; i < 4; ++i) d[i] = sum_lane_groups(d[i]);
     const float v = g == 0 ? d[0] : g == 1 ? d[1] : g == 2 ? d[2] : d[3];
     return f32x4{v, 0.f, 0.f, 0.f};
 }
