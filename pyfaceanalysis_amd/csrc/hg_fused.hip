@@ -46,6 +46,7 @@ struct FusedOptions {
     // (tools/small_batch2.py): 5-10 % of a call up to N = 128, a loss from N = 340 (one workgroup per node and slice cannot
     // match the per-layer kernels' throughput), so the default stops at 8 tiles.
     int chain_max_tiles = 8;
+    bool no_pack = false;         // HIGSFA_NO_PACK: remainder tiles as whole blocks
     int splitm_max_nodes = 4;     // experiments: HIGSFA_SPLITM_MAX
     int shape_variant = 0;        // experiments: HIGSFA_SHAPES
     static FusedOptions from_env() {
@@ -59,6 +60,7 @@ struct FusedOptions {
         if (const char* e = getenv("HIGSFA_STAMP")) o.stamp_stage = atoi(e);
         if (const char* e = getenv("HIGSFA_IG_SHAPE")) sscanf(e, "%d,%d", &o.ig_w, &o.ig_t);
         if (const char* e = getenv("HIGSFA_CHAIN_MAX_TILES")) o.chain_max_tiles = std::max(0, atoi(e));
+        o.no_pack = getenv("HIGSFA_NO_PACK") != nullptr;
         if (const char* e = getenv("HIGSFA_SPLITM_MAX")) o.splitm_max_nodes = atoi(e);
         if (const char* e = getenv("HIGSFA_SHAPES")) o.shape_variant = atoi(e);
         return o;
@@ -502,9 +504,9 @@ __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
                     for (int t = 0; t < T; ++t) d4[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int kbi = 0; kbi < KBF; ++kbi) {
-                        const int nk = __builtin_amdgcn_readfirstlane(kt[kbi].y);
-                        if constexpr (REM) gemm_block_rem<MT1, T>(wA1 + kbi * MT1 * 64, bq[kbi], z, d4, nk);
-                        else gemm_block<MT1, T>(wA1 + kbi * MT1 * 64, bq[kbi], z, nk);
+                        const int nkr = __builtin_amdgcn_readfirstlane(kt[kbi].y), nk = nkr & 255, r0 = nkr >> 8;
+                        if constexpr (REM) gemm_block_rem<MT1, T>(wA1 + kbi * MT1 * 64, bq[kbi], z, d4, nk, r0);
+                        else gemm_block<MT1, T>(wA1 + kbi * MT1 * 64, bq[kbi], z, nk, r0);
                     }
                     if constexpr (REM) {
 #pragma unroll
@@ -520,7 +522,7 @@ __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
                             for (int t = 0; t < T; ++t) bq[kbi][t] = P.in[(size_t)((in_group ? trow[t] : trow_nx[t]) + sbn) * 64 + lane];
                         }
                     }
-                    node_tail<MT1, MT2, T, REM>(P, wA2, b1 + MT1 * 16, (g0 + ln) * P.mto, z, tile, lane);
+                    node_tail<MT1, MT2, T, REM>(P, wA2, b1 + MT1 * 16, g0 + ln, z, tile, lane);
                 }
                 if (!has_next) break;
 #pragma unroll
@@ -574,8 +576,8 @@ __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
                     const int nkn = __builtin_amdgcn_readfirstlane(kbn.y);
 #pragma unroll
                     for (int t = 0; t < T; ++t) bfn[t] = P.in[(size_t)((in_group ? trow[t] : trow_nx[t]) + sbn) * 64 + lane];
-                    if constexpr (REM) gemm_block_rem<MT1, T>(wA1 + kbi * MT1 * 64, bf, z, d4, nk);
-                    else gemm_block<MT1, T>(wA1 + kbi * MT1 * 64, bf, z, nk);
+                    if constexpr (REM) gemm_block_rem<MT1, T>(wA1 + kbi * MT1 * 64, bf, z, d4, nk & 255, nk >> 8);
+                    else gemm_block<MT1, T>(wA1 + kbi * MT1 * 64, bf, z, nk & 255, nk >> 8);
 #pragma unroll
                     for (int t = 0; t < T; ++t) bf[t] = bfn[t];
                     nk = nkn;
@@ -585,7 +587,7 @@ __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
                     for (int t = 0; t < T; ++t) z[MT1 - 1][t] += rem4_rows(d4[t], g);
                 }
                 if (STAMP) ts1 = stamp_now();
-                node_tail<MT1, MT2, T, REM>(P, wA2, b1 + MT1 * 16, (g0 + ln) * P.mto, z, tile, lane);
+                node_tail<MT1, MT2, T, REM>(P, wA2, b1 + MT1 * 16, g0 + ln, z, tile, lane);
                 if (STAMP) {
                     unsigned long long ts2 = stamp_now();
                     t_g1 += ts1 - ts0;
@@ -752,6 +754,10 @@ StageFn pick_stage(int mt1, int mt2, int T, bool rem = false, int kbf = 0) {
         if (!rem && mt1 == 3 && mt2 == 3) return (StageFn)k_stage<3, 3, 2, false, false, 4>;
         if (!rem && mt1 == 2 && mt2 == 2) return (StageFn)k_stage<2, 2, 2, false, false, 4>;
     }
+    if (kbf == 3 && T == 2) {     // the same with the children's remainder tiles packed into one shared block
+        if (rem && mt1 == 3 && mt2 == 3) return (StageFn)k_stage<3, 3, 2, false, true, 3>;
+        if (rem && mt1 == 2 && mt2 == 2) return (StageFn)k_stage<2, 2, 2, false, true, 3>;
+    }
     if (rem) {      // instantiated where the synthetic and test networks need it (plan time checks the same list)
         if (mt1 == 3 && mt2 == 3) return T == 2 ? (StageFn)k_stage<3, 3, 2, false, true> : (StageFn)k_stage<3, 3, 1, false, true>;
         if (mt1 == 2 && mt2 == 2) return T == 2 ? (StageFn)k_stage<2, 2, 2, false, true> : (StageFn)k_stage<2, 2, 1, false, true>;
@@ -776,6 +782,9 @@ struct HostStage {
     int node_blocks = 0, bias_floats = 0, nk_last = 4;
     int p_max = 0, s_max = 0;   // widest first / second affine of the layer (real outputs)
     bool rem4 = false;          // last tiles of both affines in 4x4 form (k_stage REM instantiations)
+    bool pack_out = false;      // output: the remainder tiles of four sibling nodes share one block (StageParams::pack_base)
+    std::vector<int32_t> pack_slot;
+    DevBuf d_pack_slot;
     bool has_exp = false, contig4 = false, vec_ok = false;
     std::vector<ExpFunc> funcs;
     uint8_t nk2[kMaxMT][kMaxFuncs] = {};
@@ -808,11 +817,13 @@ public:
     FusedExecutor(const TNode& root, std::vector<FStage>&& fs, const FusedOptions& opt) : opt_(opt), out_dim_(root.out_dim) {
         std::vector<int32_t> prev_blk, prev_q;  // per column of the previous stage's output frame
         int prev_nb = 0;
+        bool prev_packed = false;                // previous stage stores packed remainder tiles (its consumer decodes r0)
         for (size_t si = 0; si < fs.size(); ++si) {
             FStage& st = fs[si];
             if (st.nodes[0].is_ig) {
                 if (stages_.empty()) add_gather0(st, prev_blk, prev_q, prev_nb);
                 build_ig_stage(st, prev_blk, prev_q, prev_nb);
+                prev_packed = false;
                 continue;
             }
             {
@@ -821,6 +832,7 @@ public:
                 if (table_driven) {
                     if (stages_.empty()) add_gather0(st, prev_blk, prev_q, prev_nb);
                     build_prod_stage(st, prev_blk, prev_q, prev_nb, (int)si);
+                    prev_packed = false;
                     continue;
                 }
             }
@@ -906,7 +918,7 @@ public:
             hs.bias.assign((size_t)n * hs.bias_floats, 0.f);
             if (si > 0) hs.kb1tab.assign((size_t)n * hs.kb1 * 2, 0);
 
-            std::vector<int32_t> cur_blk, cur_q;
+            std::vector<int32_t> cur_blk, cur_q, node_out;
             for (int ni = 0; ni < n; ++ni) {
                 FNode& nd = st.nodes[ni];
                 NodeK& K = nks[ni];
@@ -922,11 +934,18 @@ public:
                     for (int o = 0; o < p; ++o) bias1[o] -= av * nd.A1.W[(size_t)c * p + o];
                 }
                 for (size_t kb = 0; kb < K.src.size(); ++kb) {
+                    int r0 = 0;      // leading k-steps of a packed block that belong to other nodes' rows: skipped (k_stage only)
+                    if (si > 0 && prev_packed) {
+                        r0 = 4;
+                        for (int q = 0; q < 16; ++q)
+                            if (!K.kpos[kb * 16 + q].empty()) r0 = std::min(r0, q / 4);
+                        if (r0 >= K.nk[kb]) r0 = 0;
+                    }
                     if (si > 0) {
                         hs.kb1tab[((size_t)ni * hs.kb1 + kb) * 2] = K.src[kb];
-                        hs.kb1tab[((size_t)ni * hs.kb1 + kb) * 2 + 1] = K.nk[kb];
+                        hs.kb1tab[((size_t)ni * hs.kb1 + kb) * 2 + 1] = K.nk[kb] | (r0 << 8);
                     }
-                    hs.mfma_per_tile += (int64_t)K.nk[kb] * hs.mt1;
+                    hs.mfma_per_tile += (int64_t)(K.nk[kb] - r0) * hs.mt1;
                     for (int mt = 0; mt < hs.mt1; ++mt) {
                         float* blk = wnode + ((size_t)kb * hs.mt1 + mt) * 256;
                         for (int lane = 0; lane < 64; ++lane) {
@@ -990,10 +1009,7 @@ public:
                                 bnode[hs.mt1 * 16 + mt * 16 + gg * 4 + r] = fo < s ? (float)bias2[fo] : 0.f;
                             }
                 }
-                for (int f = 0; f < n_out; ++f) {
-                    cur_blk.push_back(ni * hs.mto + f / 16);
-                    cur_q.push_back(f % 16);
-                }
+                node_out.push_back(n_out);
             }
             // Remainder tiles (hg_fused_dev.hpp): when the last tile of BOTH affines holds 1..4 real rows, store its
             // A fragments in 4x4 form for the k_stage REM instantiations.  Only stages that always run on
@@ -1001,7 +1017,7 @@ public:
             // (k_stage_splitm takes the small ones).
             {
                 const int r1 = hs.p_max - 16 * (hs.mt1 - 1), r2 = hs.s_max - 16 * (hs.mt2 - 1);
-                hs.rem4 = si >= 2 && hs.has_exp && n > 4 && hs.mt1 == hs.mt2 && (hs.mt1 == 2 || hs.mt1 == 3) && r1 >= 1 && r1 <= 4 &&
+                hs.rem4 = si >= 1 && hs.has_exp && n > 4 && hs.mt1 == hs.mt2 && (hs.mt1 == 2 || hs.mt1 == 3) && r1 >= 1 && r1 <= 4 &&
                           r2 >= 1 && r2 <= 4 && !opt_.no_rem4;
                 if (hs.rem4) {
                     auto to4x4 = [](float* blk) {
@@ -1021,14 +1037,56 @@ public:
                     // the 4x4 tiles cost a quarter of the MFMA time of a 16x16 tile
                 }
             }
-            hs.nb_out = n * hs.mto;
+            // Packed remainder tiles: only where this stage always runs on a kernel that writes them (k_stage REM, or the fused
+            // front kernel for stage 1) and the next stage always runs on one that decodes them (k_stage: an ordinary layer of
+            // more than 16 nodes — not the split-m, chain, product or iGSFA kernels).
+            hs.pack_out = false;
+            if (hs.rem4 && n % 4 == 0 && !opt_.no_pack && si + 1 < fs.size()) {
+                const FStage& nx = fs[si + 1];
+                bool ok = nx.nodes.size() > 16;
+                for (auto& nd : nx.nodes) ok = ok && !nd.is_ig && !nd.has_prod && !nd.has_clip && nd.has_exp;
+                hs.pack_out = ok;
+            }
+            if (hs.pack_out) {
+                // which four nodes share a block: order the nodes by the node of the next layer that reads their remainder rows
+                // (first reader), so that the children of one parent — and of its neighbour — sit in one block: the parent then
+                // reads them as ONE K-block.  Any grouping is correct; this one saves loads.
+                const FStage& nx = fs[si + 1];
+                std::vector<int> col0(n, 0), reader(n, 1 << 30);
+                for (int ni = 1; ni < n; ++ni) col0[ni] = col0[ni - 1] + node_out[ni - 1];
+                std::vector<int> owner;           // output column -> node
+                for (int ni = 0; ni < n; ++ni) owner.insert(owner.end(), node_out[ni], ni);
+                for (size_t pj = 0; pj < nx.nodes.size(); ++pj)
+                    for (int c = 0; c < nx.nodes[pj].in_dim; ++c) {
+                        const int col = nx.conn[nx.nodes[pj].in_off + c];
+                        const int ni = owner[col];
+                        if (col - col0[ni] >= 16 * (hs.mto - 1)) reader[ni] = std::min(reader[ni], (int)pj);
+                    }
+                std::vector<int> order(n);
+                for (int ni = 0; ni < n; ++ni) order[ni] = ni;
+                std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return reader[a] < reader[b]; });
+                hs.pack_slot.assign(n, 0);
+                for (int rk = 0; rk < n; ++rk) hs.pack_slot[order[rk]] = rk;
+            }
+            for (int ni = 0; ni < n; ++ni)
+                for (int f = 0; f < node_out[ni]; ++f) {
+                    if (hs.pack_out && f >= 16 * (hs.mto - 1)) {
+                        cur_blk.push_back(n * (hs.mto - 1) + hs.pack_slot[ni] / 4);
+                        cur_q.push_back(4 * (hs.pack_slot[ni] % 4) + (f - 16 * (hs.mto - 1)));
+                    } else {
+                        cur_blk.push_back(ni * (hs.pack_out ? hs.mto - 1 : hs.mto) + f / 16);
+                        cur_q.push_back(f % 16);
+                    }
+                }
+            hs.nb_out = hs.pack_out ? n * (hs.mto - 1) + n / 4 : n * hs.mto;
+            prev_packed = hs.pack_out;
             prev_blk.swap(cur_blk);
             prev_q.swap(cur_q);
             prev_nb = hs.nb_out;
             max_nb_ = std::max(max_nb_, hs.nb_out);
             padded_flops_ += hs.mfma_per_tile * 2048 / 16;
             std::ostringstream os;
-            os << "fused stage " << si << (hs.rem4 ? " (4x4 remainder tiles)" : "") << ": " << hs.n_nodes << " nodes, K-blocks " << hs.kb1 << ", tiles " << hs.mt1 << "x" << hs.mt2
+            os << "fused stage " << si << (hs.rem4 ? (hs.pack_out ? " (4x4 remainder tiles, packed four to a block)" : " (4x4 remainder tiles)") : "") << ": " << hs.n_nodes << " nodes, K-blocks " << hs.kb1 << ", tiles " << hs.mt1 << "x" << hs.mt2
                << ", " << hs.mfma_per_tile << " MFMA/tile, " << hs.afrag.size() * 4 / 1024 << " KiB weights, out " << hs.nb_out
                << " blocks/tile";
             hs.name = os.str();
@@ -1071,6 +1129,7 @@ public:
             if (!s.kb1tab.empty()) s.d_kb1tab.upload(s.kb1tab.data(), s.kb1tab.size() * 4);
             if (!s.gcol.empty()) s.d_gcol.upload(s.gcol.data(), s.gcol.size() * 4);
             if (!s.etab.empty()) s.d_etab.upload(s.etab.data(), s.etab.size() * 4);
+            if (!s.pack_slot.empty()) s.d_pack_slot.upload(s.pack_slot.data(), s.pack_slot.size() * 4);
             if (!s.chunks.empty()) {
                 s.d_chunks.upload(s.chunks.data(), s.chunks.size() * sizeof(DChunk));
                 s.d_runs.upload(s.runs.data(), s.runs.size() * sizeof(DRun));
@@ -1159,6 +1218,9 @@ public:
                 R.nb_in = hs.nb_in;
                 R.nb_out = hs.nb_out;
                 R.mto = hs.mto;
+                R.pack_base = hs.pack_out ? hs.n_nodes * (hs.mto - 1) : 0;
+                R.pack_slot = (const int32_t*)hs.d_pack_slot.p;
+                R.a4x4 = hs.rem4 ? 1 : 0;
                 for (int fi = 0; fi < hs.nf; ++fi) {
                     R.funcp |= (uint32_t)hs.funcs[fi].kind << (4 * fi);
                     R.expo[fi] = (float)hs.funcs[fi].expo;
@@ -1269,8 +1331,8 @@ public:
                     // layers 0 and 1 in one persistent kernel; layer 1 writes where its own launch would
                     StageParams Q = base_params(stages_[1], nullptr, cur);
                     // second tiles of both layer-1 affines hold <= 4 real rows: 4x4x1 MFMA form (HIGSFA_NO_REM4: off)
-                    const bool rem4 = stages_[1].p_max <= 20 && stages_[1].s_max <= 20 && stages_[1].nk2[1][0] <= 1 && stages_[1].nk2[1][1] <= 1 &&
-                                      !opt_.no_rem4;
+                    const bool rem4 = stages_[1].rem4 || (stages_[1].p_max <= 20 && stages_[1].s_max <= 20 && stages_[1].nk2[1][0] <= 1 &&
+                                                          stages_[1].nk2[1][1] <= 1 && !opt_.no_rem4);
                     StageFn2 fn = pick_stage01p(x_dtype, false, rem4);
                     const int thr01 = 64 * std::max(1, (s.max_chunk_nodes + 1) / 2);   // one wave per pair of layer-0 nodes
                     // two tiles of T = 2 batch tiles + 10 vectors of 16 floats (means, biases) per wave
@@ -1384,7 +1446,8 @@ public:
                 // cost(P) = rounds of resident workgroups x (weight copy + tile iterations per workgroup)
                 const int64_t g8 = (int64_t)(n_groups + 7) / 8 * 8;
                 size_t lds_probe = (size_t)npg * s.node_blocks * 1024 + (size_t)npg * s.bias_floats * 4 + (size_t)npg * s.kb1 * 8;
-                const int kbf = (s.kb1 == 4 && T == 2 && s.mt1 == s.mt2 && (s.mt1 == 2 || s.mt1 == 3) && !opt_.no_prefetch_all) ? 4 : 0;
+                const int kbf = (T == 2 && s.mt1 == s.mt2 && (s.mt1 == 2 || s.mt1 == 3) && !opt_.no_prefetch_all)
+                                    ? (s.kb1 == 4 ? 4 : (s.kb1 == 3 && s.rem4 ? 3 : 0)) : 0;
                 const double capacity = 256.0 * resident_blocks(pick_stage(s.mt1, s.mt2, T, s.rem4, kbf), nw * 64, lds_probe);
                 int tile_parts = 1;
                 double best = 1e300;
@@ -1460,7 +1523,7 @@ public:
         d_col_base_.free();
         for (auto& s : stages_) {
             s.d_afrag.free(); s.d_bias.free(); s.d_kb1tab.free(); s.d_chunks.free();
-            s.d_runs.free(); s.d_piece.free(); s.d_koff.free(); s.d_kmean.free(); s.d_gcol.free(); s.d_etab.free();
+            s.d_runs.free(); s.d_piece.free(); s.d_koff.free(); s.d_kmean.free(); s.d_gcol.free(); s.d_etab.free(); s.d_pack_slot.free();
         }
         cap_rows_ = 0;
     }

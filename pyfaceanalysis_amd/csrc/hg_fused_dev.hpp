@@ -55,6 +55,13 @@ struct StageParams {
     int32_t lds_stride, nk_last, vec4, contig4;
     int32_t ig_has_lr, ig_folded;   // k_igsfa: residual GEMM present; folded form (first GEMM covers all output tiles, no others)
     unsigned long long* stamps;   // diagnostic build only (HIGSFA_STAMP): per-wave cycle stamps
+    // Packed remainder tiles (stages whose output ends in a tile of <= 4 real rows, 4x4 form): the last tile of FOUR sibling
+    // nodes shares one block — node n's row values in register pack_slot[n] % 4 of block pack_base + pack_slot[n] / 4 — instead of one block each;
+    // the full tiles of node n start at block n * (mto - 1).  pack_base > 0 switches it on (producer side); a consumer sees
+    // it only through its K-block table (source block, first k-step, k-steps).
+    int32_t pack_base;
+    const int32_t* pack_slot;     // [node] -> 4 * (shared block) + register: siblings under one parent of the next layer share a block
+    int32_t a4x4;                 // k_stage01p: layer-1 remainder fragments are already stored in 4x4 form
     // k_stage_prod (hg_fused_prod.hip): table-driven expansion (products, clip)
     const int2* etab;             // [neb][16] {kind << 16 | k << 8 | i, exponent bits}
     int32_t neb, has_clip;
@@ -93,15 +100,16 @@ __device__ __forceinline__ f32x4 apply_func(int func, float expo, f32x4 z) {
 // fragment is read one m-tile at a time (4 live registers instead of 4*MT): consecutive MFMAs then
 // alternate between T accumulators, which is enough to cover the 40-cycle dependent latency of
 // v_mfma_f32_16x16x4_f32.  With T == 1 all m-tiles are interleaved instead.
+// k-steps r0 .. nk-1 of the block are multiplied (r0 > 0: a packed remainder block, whose leading k-steps belong to other nodes).
 template <int MT, int T, typename WP>
-__device__ __forceinline__ void gemm_block(WP wp, const f32x4 (&b)[T], f32x4 (&acc)[MT][T], int nk) {
+__device__ __forceinline__ void gemm_block(WP wp, const f32x4 (&b)[T], f32x4 (&acc)[MT][T], int nk, int r0 = 0) {
     if constexpr (T >= 2) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const f32x4 a = wp[mt * 64];
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (r < nk) {
+                if (r >= r0 && r < nk) {
 #pragma unroll
                     for (int t = 0; t < T; ++t) acc[mt][t] = MFMA16(a[r], b[t][r], acc[mt][t]);
                 }
@@ -112,7 +120,7 @@ __device__ __forceinline__ void gemm_block(WP wp, const f32x4 (&b)[T], f32x4 (&a
         for (int mt = 0; mt < MT; ++mt) a[mt] = wp[mt * 64];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            if (r < nk) {
+            if (r >= r0 && r < nk) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -151,13 +159,13 @@ __device__ __forceinline__ f32x4 rem4_rows(f32x4 d, int g) {
 
 // gemm_block with the last m-tile in 4x4 form: tiles 0 .. MT-2 accumulate in acc, the last one in d4.
 template <int MT, int T, typename WP>
-__device__ __forceinline__ void gemm_block_rem(WP wp, const f32x4 (&b)[T], f32x4 (&acc)[MT][T], f32x4 (&d4)[T], int nk) {
+__device__ __forceinline__ void gemm_block_rem(WP wp, const f32x4 (&b)[T], f32x4 (&acc)[MT][T], f32x4 (&d4)[T], int nk, int r0 = 0) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const f32x4 a = wp[mt * 64];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            if (r < nk) {
+            if (r >= r0 && r < nk) {
 #pragma unroll
                 for (int t = 0; t < T; ++t) {
                     if (mt < MT - 1) acc[mt][t] = MFMA16(a[r], b[t][r], acc[mt][t]);
@@ -171,9 +179,10 @@ __device__ __forceinline__ void gemm_block_rem(WP wp, const f32x4 (&b)[T], f32x4
 // wA2 / b2 point at this node's A2 fragments (+lane) and bias-2 fragment; address space (LDS or
 // global) is resolved after inlining.
 template <int MT1, int MT2, int T, bool REM = false, typename WP, typename BP>
-__device__ __forceinline__ void node_tail(const StageParams& P, WP wA2, BP b2, int out_blk, f32x4 (&z)[MT1][T],
+__device__ __forceinline__ void node_tail(const StageParams& P, WP wA2, BP b2, int node, f32x4 (&z)[MT1][T],
                                           const int (&tile)[T], int lane) {
     const int g = lane >> 4;
+    const int out_blk = node * P.mto;
     if (!P.has_exp) {
 #pragma unroll
         for (int mt = 0; mt < MT1; ++mt)
@@ -213,6 +222,19 @@ __device__ __forceinline__ void node_tail(const StageParams& P, WP wA2, BP b2, i
     if constexpr (REM) {
 #pragma unroll
         for (int t = 0; t < T; ++t) y[MT2 - 1][t] += rem4_rows(d4[t], g);
+        if (P.pack_base > 0) {      // full tiles as blocks; the remainder rows into this node's register of the shared block
+#pragma unroll
+            for (int mt = 0; mt < MT2 - 1; ++mt)
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+                    if (tile[t] < P.n_tiles) P.out[((size_t)tile[t] * P.nb_out + node * (MT2 - 1) + mt) * 64 + lane] = y[mt][t];
+            const int slot = __builtin_amdgcn_readfirstlane(P.pack_slot[node]);
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+                if (tile[t] < P.n_tiles)
+                    ((float*)(P.out + ((size_t)tile[t] * P.nb_out + P.pack_base + (slot >> 2)) * 64 + lane))[slot & 3] = y[MT2 - 1][t][0];
+            return;
+        }
     }
 #pragma unroll
     for (int mt = 0; mt < MT2; ++mt)

@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(512) k_stage0(StageParams P) {
             }
             gemm_block<MT1, T>(wA1 + kbi * MT1 * 64, bf, z, kbi == P.kb1 - 1 ? P.nk_last : 4);
         }
-        node_tail<MT1, MT2, T>(P, wA2, b1 + MT1 * 16, ni * P.mto, z, tile, lane);
+        node_tail<MT1, MT2, T>(P, wA2, b1 + MT1 * 16, ni, z, tile, lane);
     }
 }
 
@@ -314,8 +314,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 3))
                 *(f32x4*)(cst + (C_QB2 + mt) * 16 + g * 4) = *(const f32x4*)(bq + 32 + mt * 16);
             }
     }
-    if constexpr (REM4) {
+    if (REM4 && !Q.a4x4) {
         // 4x4 form of the second-tile fragments: lane (g, i = lane % 4) takes row 4 i of lane group g
+        // (Q.a4x4: the planner stored them in that form already, as for the k_stage REM instantiations)
         const int src = ((lane & 48) | ((lane & 3) << 2)) << 2;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -484,11 +485,21 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 3))
 #pragma unroll
                 for (int t = 0; t < T; ++t) y1[1][t] += rem4_rows(d4[t], g);
             }
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            if (REM4 && Q.pack_base > 0) {     // packed remainder tiles (hg_fused_dev.hpp, StageParams::pack_base)
+                const int slot = __builtin_amdgcn_readfirstlane(Q.pack_slot[n1]);
 #pragma unroll
                 for (int t = 0; t < T; ++t)
-                    if (tile[t] < P.n_tiles) Q.out[((size_t)tile[t] * Q.nb_out + (size_t)n1 * Q.mto + mt) * 64 + lane] = y1[mt][t];
+                    if (tile[t] < P.n_tiles) {
+                        Q.out[((size_t)tile[t] * Q.nb_out + n1) * 64 + lane] = y1[0][t];
+                        ((float*)(Q.out + ((size_t)tile[t] * Q.nb_out + Q.pack_base + (slot >> 2)) * 64 + lane))[slot & 3] = y1[1][t][0];
+                    }
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int t = 0; t < T; ++t)
+                        if (tile[t] < P.n_tiles) Q.out[((size_t)tile[t] * Q.nb_out + (size_t)n1 * Q.mto + mt) * 64 + lane] = y1[mt][t];
+            }
             if (STAMP) { unsigned long long t = stamp_now(); t_l1 += t - ts; ts = t; ++n_it; }
         }
     }
