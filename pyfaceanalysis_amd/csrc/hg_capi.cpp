@@ -275,11 +275,15 @@ void run_host_rows(hg_flow* f, Replica& rep, const void* x, int x_dtype, int64_t
     const int64_t in_dim = f->root->in_dim;
     // ~32 MiB of caller bytes per chunk (>= 256 rows): small enough to pipeline a 4096-row float64 batch in 16 chunks,
     // large enough that a chunk's kernels are past their launch-latency floor
-    int64_t chunk = std::max<int64_t>(256, (32ll << 20) / (in_dim * (int64_t)xs));
+    // uint8 rows cannot be narrowed and need no packing: they go straight from the caller's memory (the runtime stages pageable
+    // memory itself; a second host copy into our pinned slot would only add a pass over the data) in 16 MiB chunks, so that the
+    // copy of chunk i+1 still overlaps the kernels of chunk i
+    const bool direct = x_dtype == HG_U8;
+    int64_t chunk = std::max<int64_t>(256, ((direct ? 16ll : 32ll) << 20) / (in_dim * (int64_t)xs));
     chunk = std::min(chunk, n);
     chunk = (chunk + 15) / 16 * 16;
     const size_t x_slot = (size_t)chunk * in_dim * xs, y_slot = (size_t)chunk * y_cols * ys;
-    rep.need_pinned(x_slot, y_slot);
+    rep.need_pinned(direct ? 0 : x_slot, y_slot);
     for (int b = 0; b < 2; ++b) {
         rep.dx[b].alloc(x_slot);
         rep.dy[b].alloc(y_slot);
@@ -303,11 +307,16 @@ void run_host_rows(hg_flow* f, Replica& rep, const void* x, int x_dtype, int64_t
         const int64_t r0 = ci * chunk, m = std::min(chunk, n - r0);
         if (ci >= 2) {
             unpack(ci - 2);                               // frees hy[b] (and tells us dx[b] / dy[b] are free)
-            HG_HIP(hipEventSynchronize(rep.ev_h2d[b]));   // hx[b] has left the host
+            if (!direct) HG_HIP(hipEventSynchronize(rep.ev_h2d[b]));   // hx[b] has left the host
         }
         // ---- pack (host threads), overlapping the GPU work of chunk ci - 1
         const char* xsrc = (const char*)x + (size_t)r0 * ldx * xs;
         int sent_dtype = x_dtype;
+        if (direct) {
+            if (ci >= 2) HG_HIP(hipStreamWaitEvent(rep.copy, rep.ev_out[b], 0));
+            HG_HIP(hipMemcpy2DAsync(rep.dx[b].p, (size_t)in_dim * xs, xsrc, (size_t)ldx * xs, (size_t)in_dim * xs, (size_t)m, hipMemcpyHostToDevice, rep.copy));
+            HG_HIP(hipEventRecord(rep.ev_h2d[b], rep.copy));
+        }
         if (try_narrow) {
             std::atomic<int> ok{1};
             const int tasks = (int)std::min<int64_t>(m, use_pool ? 4 * pool.size() : 1);
@@ -325,7 +334,7 @@ void run_host_rows(hg_flow* f, Replica& rep, const void* x, int x_dtype, int64_t
             if (ok.load()) sent_dtype = HG_U8;
         }
         const size_t ss = hg::dtype_size(sent_dtype);
-        if (sent_dtype == x_dtype) {      // as given: rows copied into the pinned slot (strided source allowed)
+        if (sent_dtype == x_dtype && !direct) {      // as given: rows copied into the pinned slot (strided source allowed)
             const int tasks = (int)std::min<int64_t>(m, use_pool ? 4 * pool.size() : 1);
             auto body = [&](int t) {
                 const int64_t a = m * t / tasks, e = m * (t + 1) / tasks;
@@ -336,9 +345,11 @@ void run_host_rows(hg_flow* f, Replica& rep, const void* x, int x_dtype, int64_t
             else body(0);
         }
         // ---- copy stream: H2D once the slot's previous consumer is done
-        if (ci >= 2) HG_HIP(hipStreamWaitEvent(rep.copy, rep.ev_out[b], 0));
-        HG_HIP(hipMemcpyAsync(rep.dx[b].p, rep.hx[b], (size_t)m * in_dim * ss, hipMemcpyHostToDevice, rep.copy));
-        HG_HIP(hipEventRecord(rep.ev_h2d[b], rep.copy));
+        if (!direct) {
+            if (ci >= 2) HG_HIP(hipStreamWaitEvent(rep.copy, rep.ev_out[b], 0));
+            HG_HIP(hipMemcpyAsync(rep.dx[b].p, rep.hx[b], (size_t)m * in_dim * ss, hipMemcpyHostToDevice, rep.copy));
+            HG_HIP(hipEventRecord(rep.ev_h2d[b], rep.copy));
+        }
         // ---- compute stream: kernels, features back
         HG_HIP(hipStreamWaitEvent(rep.compute, rep.ev_h2d[b], 0));
         run_on_device(f, rep.dx[b].p, sent_dtype, m, in_dim, rep.dy[b].p, y_dtype, y_cols, y_cols, rep.compute, &rep);
