@@ -47,6 +47,7 @@ struct FusedOptions {
     // match the per-layer kernels' throughput), so the default stops at 8 tiles.
     int chain_max_tiles = 8;
     bool no_pack = false;         // HIGSFA_NO_PACK: remainder tiles as whole blocks
+    int front_t = 2;              // experiments: HIGSFA_FRONT_T
     int splitm_max_nodes = 4;     // experiments: HIGSFA_SPLITM_MAX
     int shape_variant = 0;        // experiments: HIGSFA_SHAPES
     static FusedOptions from_env() {
@@ -61,6 +62,7 @@ struct FusedOptions {
         if (const char* e = getenv("HIGSFA_IG_SHAPE")) sscanf(e, "%d,%d", &o.ig_w, &o.ig_t);
         if (const char* e = getenv("HIGSFA_CHAIN_MAX_TILES")) o.chain_max_tiles = std::max(0, atoi(e));
         o.no_pack = getenv("HIGSFA_NO_PACK") != nullptr;
+        if (const char* e = getenv("HIGSFA_FRONT_T")) o.front_t = atoi(e) == 1 ? 1 : atoi(e) == 4 ? 4 : 2;
         if (const char* e = getenv("HIGSFA_SPLITM_MAX")) o.splitm_max_nodes = atoi(e);
         if (const char* e = getenv("HIGSFA_SHAPES")) o.shape_variant = atoi(e);
         return o;
@@ -1333,12 +1335,14 @@ public:
                     // second tiles of both layer-1 affines hold <= 4 real rows: 4x4x1 MFMA form (HIGSFA_NO_REM4: off)
                     const bool rem4 = stages_[1].rem4 || (stages_[1].p_max <= 20 && stages_[1].s_max <= 20 && stages_[1].nk2[1][0] <= 1 &&
                                                           stages_[1].nk2[1][1] <= 1 && !opt_.no_rem4);
-                    StageFn2 fn = pick_stage01p(x_dtype, false, rem4);
+                    const int FT = (opt_.front_t != 2 && rem4 && x_dtype == HG_F32 && (opt_.front_t == 1 || n_tiles >= 4)) ? opt_.front_t : 2;
+                    StageFn2 fn = pick_stage01p(x_dtype, false, rem4, FT);
                     const int thr01 = 64 * std::max(1, (s.max_chunk_nodes + 1) / 2);   // one wave per pair of layer-0 nodes
                     // two tiles of T = 2 batch tiles + 10 vectors of 16 floats (means, biases) per wave
-                    const size_t lds2 = (size_t)(kDoubleBuffer01 ? 2 : 1) * 2 * 16 * s.lds_stride * 4 + (size_t)(thr01 / 64) * 160 * 4;
-                    const int groups2 = (n_tiles + 1) / 2;
+                    const size_t lds2 = (size_t)(kDoubleBuffer01 ? 2 : 1) * FT * 16 * s.lds_stride * 4 + (size_t)(thr01 / 64) * 160 * 4;
+                    const int groups2 = (n_tiles + FT - 1) / FT;
                     int occ = 1;
+                    set_lds_limit((StageFn)fn, lds2);
                     {
                         auto key = std::make_tuple((const void*)fn, thr01, lds2);
                         auto it = occ_.find(key);

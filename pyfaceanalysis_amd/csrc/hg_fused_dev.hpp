@@ -273,7 +273,7 @@ typedef void (*StageFn2)(StageParams, StageParams);
 // kernels living in the other translation units
 StageFn pick_stage0(int mt1, int mt2, int T, int x_dtype);            // hg_fused_front.hip
 StageFn pick_stage0p(int x_dtype);
-StageFn2 pick_stage01p(int x_dtype, bool stamp, bool rem4);
+StageFn2 pick_stage01p(int x_dtype, bool stamp, bool rem4, int T = 2);
 StageFn pick_igsfa(int ms, int mo, int T, int kb1);                   // hg_fused_igsfa.hip
 StageFn pick_igfold(int mo, int T);
 StageFn pick_prod(int mt1, int mt2, int T);                           // hg_fused_prod.hip

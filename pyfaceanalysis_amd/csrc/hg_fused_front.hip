@@ -237,11 +237,11 @@ __global__ void __launch_bounds__(512) k_stage0p(StageParams P) {
 // blocks of layer-0 nodes 2n and 2n+1; both layer-1 affines have <= 32 outputs; same <= 2 functions.
 // REM4: both layer-1 affines have 17..20 outputs, i.e. their second 16-row tile holds only four real rows:
 // those tiles run in the 4x4 MFMA form (hg_fused_dev.hpp, "Remainder tiles"; 22 % of this kernel's MFMA time).
-template <typename XT, bool STAMP = false, bool REM4 = false>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 3))) k_stage01p(StageParams P, StageParams Q) {
+template <typename XT, bool STAMP = false, bool REM4 = false, int TT = 2>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(TT == 2 ? 3 : TT == 1 ? 4 : 2, TT == 2 ? 3 : TT == 1 ? 4 : 2))) k_stage01p(StageParams P, StageParams Q) {
     extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
     float* lds = (float*)smem;
-    constexpr int T = 2, NB = 4, NPW = 2;
+    constexpr int T = TT, NB = 2 * TT, NPW = 2;
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, g = lane >> 4, j = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ci = blockIdx.x % P.n_chunks, part = blockIdx.x / P.n_chunks;
@@ -545,7 +545,9 @@ StageFn pick_stage0(int mt1, int mt2, int T, int x_dtype) {
 StageFn pick_stage0p(int x_dtype) {
     return x_dtype == HG_U8 ? (StageFn)k_stage0p<4, uint8_t> : x_dtype == HG_F32 ? (StageFn)k_stage0p<4, float> : (StageFn)k_stage0p<4, double>;
 }
-StageFn2 pick_stage01p(int x_dtype, bool stamp, bool rem4) {
+StageFn2 pick_stage01p(int x_dtype, bool stamp, bool rem4, int T) {
+    if (T == 1 && rem4 && x_dtype == HG_F32) return (StageFn2)k_stage01p<float, false, true, 1>;     // experiment: one tile per pass, four waves per SIMD
+    if (T == 4 && rem4 && x_dtype == HG_F32) return (StageFn2)k_stage01p<float, false, true, 4>;     // experiment: four tiles per pass, two waves per SIMD
     if (rem4) {
 #ifdef HIGSFA_DIAG
         if (stamp && x_dtype == HG_F32) return (StageFn2)k_stage01p<float, true, true>;
