@@ -19,6 +19,8 @@ HOST_ONLY = {"hg_hostpack.cpp"}      # no HIP in them: built with g++ (function 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CXX = os.environ.get("CXX", "g++")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-unused-result"]
+if os.environ.get("HIGSFA_CXXFLAGS"):     # experiments: extra compiler flags (e.g. -DHG_BRANCHY_EXPANSION=0)
+    FLAGS += os.environ["HIGSFA_CXXFLAGS"].split()
 if os.environ.get("HIGSFA_DIAG"):        # diagnostic build: kernel instantiations with s_memtime stamps (tools/stamp_stages.sh)
     FLAGS.append("-DHIGSFA_DIAG")
 

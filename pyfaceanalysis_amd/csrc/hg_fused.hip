@@ -686,7 +686,7 @@ __global__ void __launch_bounds__(256) k_stage_splitm(StageParams P, int mt1n, i
             const int fk = (P.funcp >> (4 * fi)) & 15;
             const float ex = P.expo[fi];
 #pragma unroll
-            for (int t = 0; t < T; ++t) smem[((fi * mt1n + w) * T + t) * 64 + lane] = apply_func(fk, ex, z[t]);
+            for (int t = 0; t < T; ++t) smem[((fi * mt1n + w) * T + t) * 64 + lane] = apply_func_uniform(fk, ex, z[t]);
         }
     } else if (!P.has_exp) {
         return;

@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(128 * (MT1 > MT2 ? MT1 : MT2), 1) k_chain(Chai
                 if (!S.has_exp) {
                     st_sc1(rout, ((uint32_t)tile * S.nb_out + node * S.mto + m) * 1024u + lane * 16u, z);
                 } else {
-                    for (int fi = 0; fi < nf; ++fi) zs[(fi * MT1 + m) * 64 + lane] = apply_func((S.funcp >> (4 * fi)) & 15, S.expo[fi], z);
+                    for (int fi = 0; fi < nf; ++fi) zs[(fi * MT1 + m) * 64 + lane] = apply_func_uniform((S.funcp >> (4 * fi)) & 15, S.expo[fi], z);
                 }
             }
             if (S.has_exp) {

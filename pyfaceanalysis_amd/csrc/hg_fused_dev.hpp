@@ -79,6 +79,14 @@ __device__ __forceinline__ float pow_abs(float v, float p) {
     return __builtin_amdgcn_exp2f(p * __builtin_amdgcn_logf(__builtin_fabsf(v)));
 }
 
+// Element-wise expansion function on an accumulator tile; `func` is wave-uniform.
+// Two forms, chosen per kernel by measurement (same box, tools/ab_build.sh):
+//  * apply_func: the compiler if-converts the three cases, i.e. it evaluates the power for every function of the
+//    expansion, identity included (3.5x the v_log / v_exp in the front kernel's loop) — and the big sweep kernels are 2-3 %
+//    FASTER that way than with the branches below (straight-line code between the MFMA runs schedules better; the
+//    transcendental unit is otherwise idle);
+//  * apply_func_uniform: identity costs nothing, one v_log + v_exp per value behind a real scalar branch (the empty asm
+//    statement cannot be speculated); the latency-bound small kernels (k_stage_splitm, k_chain) gain 10 % from it.
 __device__ __forceinline__ f32x4 apply_func(int func, float expo, f32x4 z) {
     f32x4 e;
     if (func == (int)E_IDENTITY) {
@@ -89,6 +97,18 @@ __device__ __forceinline__ f32x4 apply_func(int func, float expo, f32x4 z) {
     } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) e[r] = __builtin_copysignf(pow_abs(z[r], expo), z[r]);
+    }
+    return e;
+}
+
+__device__ __forceinline__ f32x4 apply_func_uniform(int func, float expo, f32x4 z) {
+    if (func == (int)E_IDENTITY) return z;
+    asm volatile("" ::: "memory");
+    f32x4 e;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float p = pow_abs(z[r], expo);
+        e[r] = func == (int)E_SIGNED_POW ? __builtin_copysignf(p, z[r]) : p;
     }
     return e;
 }
