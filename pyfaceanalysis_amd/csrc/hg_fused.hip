@@ -48,6 +48,8 @@ struct FusedOptions {
     int chain_max_tiles = 8;
     bool no_pack = false;         // HIGSFA_NO_PACK: remainder tiles as whole blocks
     int front_t = 2;              // experiments: HIGSFA_FRONT_T
+    double occ_scale = 1.0;       // experiments: HIGSFA_OCC_SCALE — share of the chip a persistent kernel sizes its grid for
+    int stagger = -1;             // experiments: HIGSFA_STAGGER — with HIGSFA_SPLIT=2 the second half starts after this stage of the first
     int splitm_max_nodes = 4;     // experiments: HIGSFA_SPLITM_MAX
     int shape_variant = 0;        // experiments: HIGSFA_SHAPES
     static FusedOptions from_env() {
@@ -62,6 +64,8 @@ struct FusedOptions {
         if (const char* e = getenv("HIGSFA_IG_SHAPE")) sscanf(e, "%d,%d", &o.ig_w, &o.ig_t);
         if (const char* e = getenv("HIGSFA_CHAIN_MAX_TILES")) o.chain_max_tiles = std::max(0, atoi(e));
         o.no_pack = getenv("HIGSFA_NO_PACK") != nullptr;
+        if (const char* e = getenv("HIGSFA_OCC_SCALE")) o.occ_scale = std::max(0.1, std::min(1.0, atof(e)));
+        if (const char* e = getenv("HIGSFA_STAGGER")) o.stagger = atoi(e);
         if (const char* e = getenv("HIGSFA_FRONT_T")) o.front_t = atoi(e) == 1 ? 1 : atoi(e) == 4 ? 4 : 2;
         if (const char* e = getenv("HIGSFA_SPLITM_MAX")) o.splitm_max_nodes = atoi(e);
         if (const char* e = getenv("HIGSFA_SHAPES")) o.shape_variant = atoi(e);
@@ -1187,8 +1191,14 @@ public:
             if (m <= 0) break;
             const size_t woff = (size_t)(r0 / 16) * max_nb_ * 64;   // f32x4 elements (1 KiB blocks)
             HG_HIP(hipStreamWaitEvent(streams_[k], fork_, 0));
+            if (k > 0 && opt_.stagger >= 0) {
+                if (!stagger_ev_) HG_HIP(hipEventCreateWithFlags(&stagger_ev_, hipEventDisableTiming));
+                HG_HIP(hipStreamWaitEvent(streams_[k], stagger_ev_, 0));      // recorded by range 0 after stage `stagger`
+            }
+            stagger_stage_ = (k == 0 && split == 2) ? opt_.stagger : -1;
             run_range((const char*)x + (size_t)r0 * ldx * xs, x_dtype, m, ldx, (char*)y + (size_t)r0 * ldy * ys, y_dtype, y_cols, ldy,
                       streams_[k], nullptr, (f32x4*)bufA_.p + woff, (f32x4*)bufB_.p + woff);
+            stagger_stage_ = -1;
             HG_HIP(hipEventRecord(join_[k], streams_[k]));
             HG_HIP(hipStreamWaitEvent(st, join_[k], 0));
         }
@@ -1355,7 +1365,7 @@ public:
                             occ = it->second;
                         }
                     }
-                    P.tile_parts = std::max(1, std::min(groups2, 256 * occ / std::max(1, P.n_chunks)));
+                    P.tile_parts = std::max(1, std::min(groups2, (int)(256 * occ * opt_.occ_scale) / std::max(1, P.n_chunks)));
                     if (opt_.debug) fprintf(stderr, "[front] occ %d threads %d lds %zu chunks %d tile_parts %d\n", occ, thr01, lds2, P.n_chunks, P.tile_parts);
 #ifdef HIGSFA_DIAG
                     if (opt_.stamp_stage == 0 && x_dtype == HG_F32) {
@@ -1452,7 +1462,7 @@ public:
                 size_t lds_probe = (size_t)npg * s.node_blocks * 1024 + (size_t)npg * s.bias_floats * 4 + (size_t)npg * s.kb1 * 8;
                 const int kbf = (T == 2 && s.mt1 == s.mt2 && (s.mt1 == 2 || s.mt1 == 3) && !opt_.no_prefetch_all)
                                     ? (s.kb1 == 4 ? 4 : (s.kb1 == 3 && s.rem4 ? 3 : 0)) : 0;
-                const double capacity = 256.0 * resident_blocks(pick_stage(s.mt1, s.mt2, T, s.rem4, kbf), nw * 64, lds_probe);
+                const double capacity = 256.0 * opt_.occ_scale * resident_blocks(pick_stage(s.mt1, s.mt2, T, s.rem4, kbf), nw * 64, lds_probe);
                 int tile_parts = 1;
                 double best = 1e300;
                 for (int pp = 1; pp <= tile_groups; ++pp) {
@@ -1498,6 +1508,10 @@ public:
             }
             std::swap(cur, nxt);
             if (ev) HG_HIP(hipEventRecord(ev[e++], st));
+            if (stagger_stage_ == (int)si) {
+                if (!stagger_ev_) HG_HIP(hipEventCreateWithFlags(&stagger_ev_, hipEventDisableTiming));
+                HG_HIP(hipEventRecord(stagger_ev_, st));
+            }
         }
         const HostStage& last = stages_.back();
         unsigned grid = (unsigned)std::min<int64_t>((n * y_cols + 255) / 256, 4096);
@@ -2262,7 +2276,8 @@ private:
     DevBuf d_col_base_, bufA_, bufB_, stamp_buf_;
     std::vector<hipStream_t> streams_;
     std::vector<hipEvent_t> join_;
-    hipEvent_t fork_ = nullptr;
+    hipEvent_t fork_ = nullptr, stagger_ev_ = nullptr;
+    int stagger_stage_ = -1;
     int stamp_blocks_ = 0;
     std::map<const void*, size_t> lds_set_;
     std::map<std::tuple<const void*, int, size_t>, int> occ_;
