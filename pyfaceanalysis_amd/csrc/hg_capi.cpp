@@ -195,6 +195,7 @@ struct hg_flow {
     int& device = main.device;
     int64_t flops = 0;
     bool profiling = false, force_generic = false;
+    bool narrow = true;                  // HIGSFA_NO_NARROW, read once in hg_flow_load
     std::vector<hipEvent_t> events;
     std::vector<hg::StageProfile> prof;
 
@@ -289,7 +290,7 @@ void run_host_rows(hg_flow* f, Replica& rep, const void* x, int x_dtype, int64_t
         rep.dy[b].alloc(y_slot);
     }
     rep.exec->reserve(chunk);
-    const bool try_narrow = x_dtype != HG_U8 && !getenv("HIGSFA_NO_NARROW");
+    const bool try_narrow = x_dtype != HG_U8 && f->narrow;
     HostPool& pool = HostPool::get();
     const int64_t n_chunks = (n + chunk - 1) / chunk;
     auto unpack = [&](int64_t ci) {      // features of chunk ci: pinned slot -> caller rows
@@ -385,6 +386,7 @@ int hg_flow_load(const void* blob, size_t nbytes, int flags, hg_flow** out) {
         f->root = hg::parse_blob(blob, nbytes);
         f->flops = hg::tree_flops(*f->root);
         f->force_generic = flags & 1;
+        f->narrow = getenv("HIGSFA_NO_NARROW") == nullptr;
         if (!(flags & 1)) f->exec = hg::make_fused_executor(*f->root, &f->fused_reject);
         else f->fused_reject = "generic plan forced by caller";
         if (!f->exec) f->exec = hg::make_generic_executor(*f->root);

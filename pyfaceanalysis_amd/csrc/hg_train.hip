@@ -507,7 +507,8 @@ int train_layer_impl(const void* x_in, int x_on_host, int x_dtype, int64_t n, in
         }
         rocblas_status rs = rocblas_status_success;
         hg::DevBuf Wv;     // eigenvectors of the hand-written solver (rocSOLVER overwrites A instead)
-        const bool own_solver = d <= 16 && !getenv("HIGSFA_SYGVD") && !getenv("HIGSFA_SYGVJ");
+        static const int solver_env = getenv("HIGSFA_SYGVD") ? 2 : getenv("HIGSFA_SYGVJ") ? 1 : 0;   // read once per process
+        const bool own_solver = d <= 16 && solver_env == 0;
         rocblas_handle h = nullptr;
         if (!own_solver && rocblas_create_handle(&h) != rocblas_status_success) hg::fail(HG_ERR_DEVICE, "rocblas_create_handle failed");
         HG_HIP(hipEventRecord(e1, nullptr));
@@ -516,7 +517,7 @@ int train_layer_impl(const void* x_in, int x_on_host, int x_dtype, int64_t n, in
             hipLaunchKernelGGL(k_sygv16, (unsigned)n_nodes, 64, 0, nullptr, (const double*)A.p, (const double*)B.p, d, (double*)W.p,
                                (double*)Wv.p, (int*)info.p);
             HG_HIP(hipGetLastError());
-        } else if (getenv("HIGSFA_SYGVD")) {
+        } else if (solver_env == 2) {
             rs = rocsolver_dsygvd_strided_batched(h, rocblas_eform_ax, rocblas_evect_original, rocblas_fill_upper, d, (double*)A.p, d, dd,
                                                   (double*)B.p, d, dd, (double*)W.p, d, (double*)E.p, d, (rocblas_int*)info.p, n_nodes);
         } else {

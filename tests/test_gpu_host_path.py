@@ -39,9 +39,11 @@ def test_pipelined_chunks_narrowing_and_fallthrough(native_lib, nets, monkeypatc
     assert np.array_equal(yf[~touched], y8[~touched])
     assert rel_err(yf[touched], oracle.execute_flow(nodes, xf[touched])) <= TOL
     # narrowing switched off: same bits
-    monkeypatch.setenv("HIGSFA_NO_NARROW", "1")
-    assert np.array_equal(flow.execute(xi.astype(np.float64)), y8)
+    monkeypatch.setenv("HIGSFA_NO_NARROW", "1")          # read once, when a flow is loaded
+    wide_flow = Flow(nodes)
     monkeypatch.delenv("HIGSFA_NO_NARROW")
+    assert np.array_equal(wide_flow.execute(xi.astype(np.float64)), y8)
+    wide_flow.close()
     # strided rows (ldx > input_dim) and the first-k-columns form through the same staging
     wide = np.zeros((n, 260), dtype=np.float32)
     wide[:, 2:258] = xi
