@@ -41,15 +41,13 @@ using namespace fused;
 // execute path.  None changes results beyond rounding.
 struct FusedOptions {
     bool no_rem4 = false, ig_nofold = false, ig_resident = false, debug = false, no_prefetch_all = false;
-    int split = 1, stamp_stage = -1, ig_w = 0, ig_t = 0;
+    int stamp_stage = -1, ig_w = 0, ig_t = 0;
     // batches of up to this many 16-row tiles run the top layers as one persistent launch (0: never).  Measured on U11L-128
     // (tools/small_batch2.py): 5-10 % of a call up to N = 128, a loss from N = 340 (one workgroup per node and slice cannot
     // match the per-layer kernels' throughput), so the default stops at 8 tiles.
     int chain_max_tiles = 8;
     bool no_pack = false;         // HIGSFA_NO_PACK: remainder tiles as whole blocks
-    int front_t = 2;              // experiments: HIGSFA_FRONT_T
-    double occ_scale = 1.0;       // experiments: HIGSFA_OCC_SCALE — share of the chip a persistent kernel sizes its grid for
-    int stagger = -1;             // experiments: HIGSFA_STAGGER — with HIGSFA_SPLIT=2 the second half starts after this stage of the first
+    bool no_fspec = false;        // HIGSFA_NO_FSPEC: front kernel without the compile-time (identity, abs-power) expansion
     int splitm_max_nodes = 4;     // experiments: HIGSFA_SPLITM_MAX
     int shape_variant = 0;        // experiments: HIGSFA_SHAPES
     static FusedOptions from_env() {
@@ -59,14 +57,11 @@ struct FusedOptions {
         o.ig_resident = getenv("HIGSFA_IG_RESIDENT") != nullptr;
         o.debug = getenv("HIGSFA_DEBUG") != nullptr;
         o.no_prefetch_all = getenv("HIGSFA_NO_PREFETCH_ALL") != nullptr;
-        if (const char* e = getenv("HIGSFA_SPLIT")) o.split = std::max(1, std::min(4, atoi(e)));
         if (const char* e = getenv("HIGSFA_STAMP")) o.stamp_stage = atoi(e);
         if (const char* e = getenv("HIGSFA_IG_SHAPE")) sscanf(e, "%d,%d", &o.ig_w, &o.ig_t);
         if (const char* e = getenv("HIGSFA_CHAIN_MAX_TILES")) o.chain_max_tiles = std::max(0, atoi(e));
         o.no_pack = getenv("HIGSFA_NO_PACK") != nullptr;
-        if (const char* e = getenv("HIGSFA_OCC_SCALE")) o.occ_scale = std::max(0.1, std::min(1.0, atof(e)));
-        if (const char* e = getenv("HIGSFA_STAGGER")) o.stagger = atoi(e);
-        if (const char* e = getenv("HIGSFA_FRONT_T")) o.front_t = atoi(e) == 1 ? 1 : atoi(e) == 4 ? 4 : 2;
+        o.no_fspec = getenv("HIGSFA_NO_FSPEC") != nullptr;
         if (const char* e = getenv("HIGSFA_SPLITM_MAX")) o.splitm_max_nodes = atoi(e);
         if (const char* e = getenv("HIGSFA_SHAPES")) o.shape_variant = atoi(e);
         return o;
@@ -610,8 +605,11 @@ __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
         }
     }
     if (STAMP && lane == 0 && P.stamps) {
-        unsigned long long* o = P.stamps + ((size_t)blockIdx.x * 8 + wave) * 6;
-        o[5] = __builtin_amdgcn_s_memrealtime() - rt0;
+        unsigned long long* o = P.stamps + ((size_t)blockIdx.x * 8 + wave) * 8;
+        const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
+        o[5] = rt1 - rt0;
+        o[6] = rt0;
+        o[7] = rt1;
         o[0] = t_copy;
         o[1] = t_g1;
         o[2] = t_tail;
@@ -1160,48 +1158,12 @@ public:
         cap_rows_ = std::max(cap_rows_, tiles * 16);
     }
 
-    // Experiment (HIGSFA_SPLIT=k): cut large batches into k row ranges that run the whole stage
-    // sequence on separate internal streams, hoping the launch ramp / drain of one range's kernels
-    // overlaps the steady state of the other's.  Ranges use disjoint slices of the workspace; the
-    // caller's stream waits for all of them.
     void run(const void* x, int x_dtype, int64_t n, int64_t ldx, void* y, int y_dtype, int64_t y_cols, int64_t ldy,
              hipStream_t st, hipEvent_t* ev) override {
         if (n > cap_rows_) reserve(n);
-        // measured on MI355X at N = 4096: split 1 -> 0.656 ms, 2 -> 0.691, 3 -> 0.825, 4 -> 0.780: the
-        // persistent kernels are sized to fill the chip, two of them only compete.  Off by default.
-        const int split = opt_.split;
-        if (ev || n < 2048 || split == 1) {
-            run_range(x, x_dtype, n, ldx, y, y_dtype, y_cols, ldy, st, ev, (f32x4*)bufA_.p, (f32x4*)bufB_.p);
-            return;
-        }
-        while ((int)streams_.size() < split) {
-            hipStream_t s2;
-            HG_HIP(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
-            streams_.push_back(s2);
-            hipEvent_t e2;
-            HG_HIP(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
-            join_.push_back(e2);
-        }
-        if (!fork_) HG_HIP(hipEventCreateWithFlags(&fork_, hipEventDisableTiming));
-        HG_HIP(hipEventRecord(fork_, st));
-        const int64_t per = ((n + split - 1) / split + 31) / 32 * 32;
-        const size_t xs = dtype_size(x_dtype), ys = dtype_size(y_dtype);
-        for (int k = 0; k < split; ++k) {
-            const int64_t r0 = (int64_t)k * per, m = std::min(per, n - r0);
-            if (m <= 0) break;
-            const size_t woff = (size_t)(r0 / 16) * max_nb_ * 64;   // f32x4 elements (1 KiB blocks)
-            HG_HIP(hipStreamWaitEvent(streams_[k], fork_, 0));
-            if (k > 0 && opt_.stagger >= 0) {
-                if (!stagger_ev_) HG_HIP(hipEventCreateWithFlags(&stagger_ev_, hipEventDisableTiming));
-                HG_HIP(hipStreamWaitEvent(streams_[k], stagger_ev_, 0));      // recorded by range 0 after stage `stagger`
-            }
-            stagger_stage_ = (k == 0 && split == 2) ? opt_.stagger : -1;
-            run_range((const char*)x + (size_t)r0 * ldx * xs, x_dtype, m, ldx, (char*)y + (size_t)r0 * ldy * ys, y_dtype, y_cols, ldy,
-                      streams_[k], nullptr, (f32x4*)bufA_.p + woff, (f32x4*)bufB_.p + woff);
-            stagger_stage_ = -1;
-            HG_HIP(hipEventRecord(join_[k], streams_[k]));
-            HG_HIP(hipStreamWaitEvent(st, join_[k], 0));
-        }
+        // (Cutting a batch into row ranges on separate streams, plain or staggered, was measured and dropped: 0.69-0.84 ms
+        // against 0.65 at N = 4096 — DESIGN.md §6.1.)
+        run_range(x, x_dtype, n, ldx, y, y_dtype, y_cols, ldy, st, ev, (f32x4*)bufA_.p, (f32x4*)bufB_.p);
     }
 
     void run_range(const void* x, int x_dtype, int64_t n, int64_t ldx, void* y, int y_dtype, int64_t y_cols, int64_t ldy,
@@ -1339,17 +1301,22 @@ public:
                 const int T = (n_tiles >= 4 && s.mt1 * s.mt2 <= 4) ? 4 : 1;
                 const int groups = (n_tiles + T - 1) / T;
                 size_t lds_bytes = (size_t)T * 16 * s.lds_stride * 4;
-                if (fuse01_ && P.vec4 && n_tiles >= 2) {
+                bool rem4 = false, fspec = false;
+                if (fuse01_) {
+                    // second tiles of both layer-1 affines hold <= 4 real rows: 4x4x1 MFMA form (HIGSFA_NO_REM4: off)
+                    rem4 = stages_[1].rem4 || (stages_[1].p_max <= 20 && stages_[1].s_max <= 20 && stages_[1].nk2[1][0] <= 1 &&
+                                               stages_[1].nk2[1][1] <= 1 && !opt_.no_rem4);
+                    auto id_pow = [](const HostStage& hs) { return hs.nf == 2 && hs.funcs[0].kind == E_IDENTITY && hs.funcs[1].kind == E_ABS_POW; };
+                    fspec = rem4 && id_pow(s) && id_pow(stages_[1]) && !opt_.no_fspec;
+                }
+                const int FT = stage01p_tiles(rem4, fspec);      // batch tiles per pass of the fused front kernel
+                if (fuse01_ && P.vec4 && n_tiles >= FT) {
                     // layers 0 and 1 in one persistent kernel; layer 1 writes where its own launch would
                     StageParams Q = base_params(stages_[1], nullptr, cur);
-                    // second tiles of both layer-1 affines hold <= 4 real rows: 4x4x1 MFMA form (HIGSFA_NO_REM4: off)
-                    const bool rem4 = stages_[1].rem4 || (stages_[1].p_max <= 20 && stages_[1].s_max <= 20 && stages_[1].nk2[1][0] <= 1 &&
-                                                          stages_[1].nk2[1][1] <= 1 && !opt_.no_rem4);
-                    const int FT = (opt_.front_t != 2 && rem4 && x_dtype == HG_F32 && (opt_.front_t == 1 || n_tiles >= 4)) ? opt_.front_t : 2;
-                    StageFn2 fn = pick_stage01p(x_dtype, false, rem4, FT);
+                    StageFn2 fn = pick_stage01p(x_dtype, false, rem4, fspec);
                     const int thr01 = 64 * std::max(1, (s.max_chunk_nodes + 1) / 2);   // one wave per pair of layer-0 nodes
                     // two tiles of T = 2 batch tiles + 10 vectors of 16 floats (means, biases) per wave
-                    const size_t lds2 = (size_t)(kDoubleBuffer01 ? 2 : 1) * FT * 16 * s.lds_stride * 4 + (size_t)(thr01 / 64) * 160 * 4;
+                    const size_t lds2 = (size_t)(kDoubleBuffer01 ? 2 : 1) * FT * 16 * s.lds_stride * 4 + (size_t)(thr01 / 64) * 160 * 4 + 16;   // + tile-group queue slots
                     const int groups2 = (n_tiles + FT - 1) / FT;
                     int occ = 1;
                     set_lds_limit((StageFn)fn, lds2);
@@ -1365,25 +1332,49 @@ public:
                             occ = it->second;
                         }
                     }
-                    P.tile_parts = std::max(1, std::min(groups2, (int)(256 * occ * opt_.occ_scale) / std::max(1, P.n_chunks)));
+                    P.tile_parts = std::max(1, std::min(groups2, 256 * occ / std::max(1, P.n_chunks)));
                     if (opt_.debug) fprintf(stderr, "[front] occ %d threads %d lds %zu chunks %d tile_parts %d\n", occ, thr01, lds2, P.n_chunks, P.tile_parts);
 #ifdef HIGSFA_DIAG
                     if (opt_.stamp_stage == 0 && x_dtype == HG_F32) {
-                        fn = pick_stage01p(HG_F32, true, rem4);
+                        fn = pick_stage01p(HG_F32, true, rem4, fspec);
                         stamp_blocks_ = P.n_chunks * P.tile_parts;
-                        stamp_buf_.alloc((size_t)stamp_blocks_ * 8 * 8 * 8);
+                        stamp_buf_.alloc((size_t)stamp_blocks_ * 8 * 12 * 8);
                         HG_HIP(hipMemsetAsync(stamp_buf_.p, 0, stamp_buf_.bytes, st));
                         P.stamps = (unsigned long long*)stamp_buf_.p;
                     }
 #endif
+                    P.work_ctr = work_counters(P.n_chunks, st);
+                    P.work_base = work_base_;
+                    work_base_ += (uint32_t)groups2;      // what this launch adds to every counter (StageParams::work_ctr)
                     hipLaunchKernelGGL(fn, (unsigned)(P.n_chunks * P.tile_parts), thr01, lds2, st, P, Q);
                     if (P.stamps) {
                         HG_HIP(hipStreamSynchronize(st));
-                        std::vector<unsigned long long> h((size_t)stamp_blocks_ * 8 * 8);
+                        std::vector<unsigned long long> h((size_t)stamp_blocks_ * 8 * 12);
                         HG_HIP(hipMemcpy(h.data(), stamp_buf_.p, h.size() * 8, hipMemcpyDeviceToHost));
                         double a[7] = {0, 0, 0, 0, 0, 0, 0}, nwv = 0;
-                        for (size_t i = 0; i < h.size(); i += 8)
-                            if (h[i + 4]) { for (int k = 0; k < 7; ++k) a[k] += h[i + k]; nwv += 1; }
+                        unsigned long long lo[3] = {~0ull, ~0ull, ~0ull}, hi[3] = {0, 0, 0};     // wall clock (100 MHz): entry, loop start, end
+                        for (size_t i = 0; i < h.size(); i += 12)
+                            if (h[i + 4]) {
+                                for (int k = 0; k < 7; ++k) a[k] += h[i + k];
+                                nwv += 1;
+                                for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], h[i + 7 + k]); hi[k] = std::max(hi[k], h[i + 7 + k]); }
+                            }
+                        {
+                            double xs[8][4] = {}, ps[16][3] = {};
+                            for (size_t i = 0, w = 0; i < h.size(); i += 12, ++w)
+                                if (h[i + 4]) {
+                                    const int blk = (int)(w / 8), xc = blk % 8, pt = std::min(15, blk / P.n_chunks);
+                                    const double life = (h[i + 9] - h[i + 8]) * 0.01, clk = (double)h[i + 4] / (double)h[i + 5] * 100.0;
+                                    xs[xc][0] += 1; xs[xc][1] += life; xs[xc][2] = std::max(xs[xc][2], life); xs[xc][3] += clk;
+                                    ps[pt][0] += 1; ps[pt][1] += life; ps[pt][2] = std::max(ps[pt][2], life);
+                                }
+                            for (int k = 0; k < 8; ++k)
+                                if (xs[k][0] > 0) fprintf(stderr, "[stamp stage 0+1] xcd %d: waves %.0f loop us mean %.1f max %.1f clock %.0f MHz\n", k, xs[k][0], xs[k][1] / xs[k][0], xs[k][2], xs[k][3] / xs[k][0]);
+                            for (int k = 0; k < 16; ++k)
+                                if (ps[k][0] > 0) fprintf(stderr, "[stamp stage 0+1] part %d: waves %.0f loop us mean %.1f max %.1f\n", k, ps[k][0], ps[k][1] / ps[k][0], ps[k][2]);
+                        }
+                        fprintf(stderr, "[stamp stage 0+1] wall clock, us after the first wave's entry: entries until %.1f, loop starts %.1f..%.1f, ends %.1f..%.1f\n",
+                                (hi[0] - lo[0]) * 0.01, (lo[1] - lo[0]) * 0.01, (hi[1] - lo[0]) * 0.01, (lo[2] - lo[0]) * 0.01, (hi[2] - lo[0]) * 0.01);
                         fprintf(stderr, "[stamp stage 0+1] waves %.0f clock %.0f MHz lifetime %.1f us, iterations %.1f; cycles per iteration: "
                                         "lds-write+barrier %.0f, fetch issue %.0f, layer0 %.0f, layer1+store %.0f (sum %.0f)\n",
                                 nwv, a[4] / a[5] * 100.0, a[5] / nwv / 100.0, a[6] / nwv, a[0] / a[6], a[1] / a[6], a[2] / a[6], a[3] / a[6],
@@ -1462,7 +1453,7 @@ public:
                 size_t lds_probe = (size_t)npg * s.node_blocks * 1024 + (size_t)npg * s.bias_floats * 4 + (size_t)npg * s.kb1 * 8;
                 const int kbf = (T == 2 && s.mt1 == s.mt2 && (s.mt1 == 2 || s.mt1 == 3) && !opt_.no_prefetch_all)
                                     ? (s.kb1 == 4 ? 4 : (s.kb1 == 3 && s.rem4 ? 3 : 0)) : 0;
-                const double capacity = 256.0 * opt_.occ_scale * resident_blocks(pick_stage(s.mt1, s.mt2, T, s.rem4, kbf), nw * 64, lds_probe);
+                const double capacity = 256.0 * resident_blocks(pick_stage(s.mt1, s.mt2, T, s.rem4, kbf), nw * 64, lds_probe);
                 int tile_parts = 1;
                 double best = 1e300;
                 for (int pp = 1; pp <= tile_groups; ++pp) {
@@ -1486,7 +1477,7 @@ public:
                 if (opt_.stamp_stage == (int)si && s.mt1 == s.mt2 && (s.mt1 == 4 || s.mt1 == 3) && T == 2 && !s.rem4 && kbf == 0) {
                     // diagnostic instantiation with s_memtime stamps (never used in timed runs)
                     fn = s.mt1 == 4 ? (StageFn)k_stage<4, 4, 2, true> : (StageFn)k_stage<3, 3, 2, true>;
-                    stamp_buf_.alloc((size_t)blocks * 8 * 6 * 8);
+                    stamp_buf_.alloc((size_t)blocks * 8 * 8 * 8);
                     HG_HIP(hipMemsetAsync(stamp_buf_.p, 0, stamp_buf_.bytes, st));
                     P.stamps = (unsigned long long*)stamp_buf_.p;
                     stamp_blocks_ = (int)blocks;
@@ -1496,11 +1487,22 @@ public:
                 hipLaunchKernelGGL(fn, (unsigned)blocks, nw * 64, lds_bytes, st, P);
                 if (P.stamps) {
                     HG_HIP(hipStreamSynchronize(st));
-                    std::vector<unsigned long long> h((size_t)stamp_blocks_ * 8 * 6);
+                    std::vector<unsigned long long> h((size_t)stamp_blocks_ * 8 * 8);
                     HG_HIP(hipMemcpy(h.data(), stamp_buf_.p, h.size() * 8, hipMemcpyDeviceToHost));
                     double c = 0, g1 = 0, tl = 0, all = 0, it = 0, nwv = 0, rt = 0;
-                    for (size_t i = 0; i < h.size(); i += 6)
-                        if (h[i + 3]) { c += h[i]; g1 += h[i + 1]; tl += h[i + 2]; all += h[i + 3]; it += h[i + 4]; rt += h[i + 5]; nwv += 1; }
+                    unsigned long long lo0 = ~0ull, hi0 = 0, lo1 = ~0ull, hi1 = 0;
+                    std::vector<unsigned long long> ends;
+                    for (size_t i = 0; i < h.size(); i += 8)
+                        if (h[i + 3]) {
+                            c += h[i]; g1 += h[i + 1]; tl += h[i + 2]; all += h[i + 3]; it += h[i + 4]; rt += h[i + 5]; nwv += 1;
+                            lo0 = std::min(lo0, h[i + 6]); hi0 = std::max(hi0, h[i + 6]); lo1 = std::min(lo1, h[i + 7]); hi1 = std::max(hi1, h[i + 7]);
+                            ends.push_back(h[i + 7]);
+                        }
+                    std::sort(ends.begin(), ends.end());
+                    if (!ends.empty())
+                        fprintf(stderr, "[stamp stage %d] wall clock, us after the first wave's start: starts until %.1f, ends %.1f (10%%) %.1f (50%%) %.1f (90%%) %.1f (last); grid %lld blocks x %d waves\n",
+                                (int)si, (hi0 - lo0) * 0.01, (ends[ends.size() / 10] - lo0) * 0.01, (ends[ends.size() / 2] - lo0) * 0.01,
+                                (ends[ends.size() * 9 / 10] - lo0) * 0.01, (hi1 - lo0) * 0.01, (long long)blocks, nw);
                     fprintf(stderr, "[stamp stage %d] in-kernel clock %.0f MHz, wave lifetime %.1f us\n", (int)si, all / rt * 100.0, rt / nwv / 100.0);
                     fprintf(stderr, "[stamp stage %d] waves %.0f  avg cycles/wave: total %.0f  copy+barrier %.0f  gemm1 %.0f  tail %.0f  node-iterations %.1f  (per iteration: gemm1 %.0f tail %.0f)\n",
                             (int)si, nwv, all / nwv, c / nwv, g1 / nwv, tl / nwv, it / nwv, g1 / it, tl / it);
@@ -1508,10 +1510,6 @@ public:
             }
             std::swap(cur, nxt);
             if (ev) HG_HIP(hipEventRecord(ev[e++], st));
-            if (stagger_stage_ == (int)si) {
-                if (!stagger_ev_) HG_HIP(hipEventCreateWithFlags(&stagger_ev_, hipEventDisableTiming));
-                HG_HIP(hipEventRecord(stagger_ev_, st));
-            }
         }
         const HostStage& last = stages_.back();
         unsigned grid = (unsigned)std::min<int64_t>((n * y_cols + 255) / 256, 4096);
@@ -1528,16 +1526,11 @@ public:
     }
 
     void release() override {
-        for (auto s2 : streams_) (void)hipStreamDestroy(s2);
-        for (auto e2 : join_) (void)hipEventDestroy(e2);
-        if (fork_) (void)hipEventDestroy(fork_);
-        streams_.clear();
-        join_.clear();
-        fork_ = nullptr;
         bufA_.free();
         bufB_.free();
         chain_buf_.free();
         chain_flags_.free();
+        work_ctr_.free();
         d_col_base_.free();
         for (auto& s : stages_) {
             s.d_afrag.free(); s.d_bias.free(); s.d_kb1tab.free(); s.d_chunks.free();
@@ -1557,6 +1550,17 @@ private:
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)fn, threads, lds) != hipSuccess || nb < 1) nb = 1;
         occ_[key] = nb;
         return nb;
+    }
+
+    // Counters of the dynamic tile-group queues (16 words apart); zeroed once, then only ever advanced (work_base_).
+    uint32_t* work_counters(int n_chunks, hipStream_t st) {
+        const size_t need = (size_t)n_chunks * 64;
+        if (work_ctr_.bytes < need) {
+            work_ctr_.alloc(std::max<size_t>(need, 64 * 1024));
+            HG_HIP(hipMemsetAsync(work_ctr_.p, 0, work_ctr_.bytes, st));
+            work_base_ = 0;
+        }
+        return (uint32_t*)work_ctr_.p;
     }
 
     void set_lds_limit(StageFn fn, size_t bytes) {
@@ -2273,11 +2277,8 @@ private:
     bool s0_transpose_ = false, fuse01_ = false;
     std::vector<HostStage> stages_;
     std::vector<int32_t> col_base_;
-    DevBuf d_col_base_, bufA_, bufB_, stamp_buf_;
-    std::vector<hipStream_t> streams_;
-    std::vector<hipEvent_t> join_;
-    hipEvent_t fork_ = nullptr, stagger_ev_ = nullptr;
-    int stagger_stage_ = -1;
+    DevBuf d_col_base_, bufA_, bufB_, stamp_buf_, work_ctr_;
+    uint32_t work_base_ = 0;
     int stamp_blocks_ = 0;
     std::map<const void*, size_t> lds_set_;
     std::map<std::tuple<const void*, int, size_t>, int> occ_;

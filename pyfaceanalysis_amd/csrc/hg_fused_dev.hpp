@@ -66,6 +66,14 @@ struct StageParams {
     const int2* etab;             // [neb][16] {kind << 16 | k << 8 | i, exponent bits}
     int32_t neb, has_clip;
     float clip_lo, clip_hi;
+    // Dynamic tile-group queue of the persistent sweep kernels: one counter per node chunk (16 words apart).  A workgroup's
+    // first tile group is its `part`; every further one is tile_parts + (atomicAdd(counter, 1) - work_base), taken two
+    // iterations ahead so that the atomic's round trip is never waited for.  Counters are never reset: every workgroup
+    // stops at its first failing grab, so a launch advances each counter by exactly tile_groups and the host adds that
+    // to work_base (32-bit wrap-around is harmless).  Why: the SIMD arbiter favours the oldest wave, so with a static
+    // split the first workgroup of a CU finishes 25 % before the third and the kernel ends with a third of its waves.
+    uint32_t* work_ctr;
+    uint32_t work_base;
 };
 
 __device__ __forceinline__ unsigned long long stamp_now() {
@@ -77,6 +85,13 @@ __device__ __forceinline__ unsigned long long stamp_now() {
 __device__ __forceinline__ float pow_abs(float v, float p) {
     // |v|^p = exp2(p * log2|v|); v = 0 -> log2 = -inf -> exp2 = 0 exactly
     return __builtin_amdgcn_exp2f(p * __builtin_amdgcn_logf(__builtin_fabsf(v)));
+}
+
+__device__ __forceinline__ f32x4 pow_abs4(f32x4 z, float p) {
+    f32x4 e;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) e[r] = pow_abs(z[r], p);
+    return e;
 }
 
 // Element-wise expansion function on an accumulator tile; `func` is wave-uniform.
@@ -293,7 +308,8 @@ typedef void (*StageFn2)(StageParams, StageParams);
 // kernels living in the other translation units
 StageFn pick_stage0(int mt1, int mt2, int T, int x_dtype);            // hg_fused_front.hip
 StageFn pick_stage0p(int x_dtype);
-StageFn2 pick_stage01p(int x_dtype, bool stamp, bool rem4, int T = 2);
+StageFn2 pick_stage01p(int x_dtype, bool stamp, bool rem4, bool fspec);
+int stage01p_tiles(bool rem4, bool fspec);
 StageFn pick_igsfa(int ms, int mo, int T, int kb1);                   // hg_fused_igsfa.hip
 StageFn pick_igfold(int mo, int T);
 StageFn pick_prod(int mt1, int mt2, int T);                           // hg_fused_prod.hip

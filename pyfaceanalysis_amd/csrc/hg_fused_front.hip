@@ -237,10 +237,15 @@ __global__ void __launch_bounds__(512) k_stage0p(StageParams P) {
 // blocks of layer-0 nodes 2n and 2n+1; both layer-1 affines have <= 32 outputs; same <= 2 functions.
 // REM4: both layer-1 affines have 17..20 outputs, i.e. their second 16-row tile holds only four real rows:
 // those tiles run in the 4x4 MFMA form (hg_fused_dev.hpp, "Remainder tiles"; 22 % of this kernel's MFMA time).
-template <typename XT, bool STAMP = false, bool REM4 = false, int TT = 2>
+// FSPEC = 1: both layers expand with exactly (identity, |x|^p) — the expansion of every preset network — known at compile
+// time: no function-kind branches, the second-tile k-step count of a REM4 layer 1 is the constant 1, and the loop body is
+// one basic block in which the scheduler can place a wave's expansion arithmetic in the shadow of its own MFMAs.
+template <typename XT, bool STAMP = false, bool REM4 = false, int TT = 2, int FSPEC = 0>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(TT == 2 ? 3 : TT == 1 ? 4 : 2, TT == 2 ? 3 : TT == 1 ? 4 : 2))) k_stage01p(StageParams P, StageParams Q) {
     extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
     float* lds = (float*)smem;
+    unsigned long long rt_entry = 0;
+    if (STAMP) rt_entry = __builtin_amdgcn_s_memrealtime();
     constexpr int T = TT, NB = 2 * TT, NPW = 2;
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, g = lane >> 4, j = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -347,6 +352,22 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(TT == 
         }
     };
     f32x4 v[NB];
+    // tile-group queue (StageParams::work_ctr): this workgroup's first group is `part`, the rest are grabbed by thread 0
+    // two iterations ahead and passed through an LDS slot that alternates with the tile buffers
+    int* qslot = (int*)(lds + (kDoubleBuffer01 ? 2 : 1) * (T * 16 * stride) + (nthr >> 6) * 160);
+    uint32_t* qctr = P.work_ctr + (size_t)ci * 16;
+    const uint32_t q_dyn = (uint32_t)(n_groups - P.tile_parts);
+    // increment-with-wrap rather than fetch_add: the compiler's atomic optimizer rewrites the latter into a wave-wide reduction +
+    // readfirstlane, which waits for the result on the spot.  The raw return value is kept as it is until it is needed (one
+    // iteration later), so that no wait is placed next to the atomic.
+    auto grab_raw = [&]() -> uint32_t { return __builtin_amdgcn_atomic_inc32(qctr, 0xffffffffu, __ATOMIC_RELAXED, "agent"); };
+    auto grab_group = [&](uint32_t raw) -> int {
+        const uint32_t k = raw - P.work_base;
+        return k < q_dyn ? (int)(P.tile_parts + k) : n_groups;
+    };
+    uint32_t q_raw = 0;                        // thread 0: the grab in flight (group of the iteration after next)
+    bool q_more = tid == 0;                    // thread 0: no grab has failed yet
+    if (q_more) q_raw = grab_raw();
     if (part < n_groups) fetch(part, v);
     // two LDS tiles, used alternately: one barrier per tile group is enough (a wave that writes tile
     // i+1 has passed barrier i, i.e. every wave has finished reading tile i-1, which shares its buffer)
@@ -359,21 +380,52 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(TT == 
         t_all0 = stamp_now();
         rt0 = __builtin_amdgcn_s_memrealtime();
     }
-    for (int grp = part; grp < n_groups; grp += P.tile_parts) {
+    // Deferred stores: gfx950 returns loads and stores out of order with respect to each other, so waiting for the prefetched
+    // sub-image rows (vmcnt(0)) would also wait for whatever stores were issued since — a full write round trip per tile group
+    // when the results are stored at the end of an iteration.  They are therefore kept in registers and stored one iteration
+    // later, right after the barrier, together with the next prefetch: every wait then sees only stores that are a whole
+    // compute phase old.
+    constexpr bool DEFER = REM4 && FSPEC == 1;      // the generic instantiation has no registers to spare: it stores at once
+    f32x4 st_y0[T];
+    float st_y1[T];
+    int st_grp = -1;
+    const int pk_slot = (REM4 && Q.pack_base > 0) ? __builtin_amdgcn_readfirstlane(Q.pack_slot[n1]) : 0;
+    auto flush = [&]() {
+        if (st_grp < 0) return;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int tl = st_grp * T + t;
+            if (tl < P.n_tiles) {
+                Q.out[((size_t)tl * Q.nb_out + n1) * 64 + lane] = st_y0[t];
+                ((float*)(Q.out + ((size_t)tl * Q.nb_out + Q.pack_base + (pk_slot >> 2)) * 64 + lane))[pk_slot & 3] = st_y1[t];
+            }
+        }
+        st_grp = -1;
+    };
+    for (int grp = part; grp < n_groups;) {
         if (STAMP) ts = stamp_now();
+        const int slot = flip;
         if (kDoubleBuffer01) {
             lds = lds0 + flip * buf_words;
-            flip ^= 1;
         } else {
             __syncthreads();   // single tile: every wave is done with the previous tile group
         }
+        flip ^= 1;
 #pragma unroll
         for (int k = 0; k < NB; ++k)
             if (p_dst[k] >= 0) *(f32x4*)(lds + (p_dst[k] & 0xffffff)) = v[k];
         if (tid < T * 16) lds[tid * stride + stride - 1] = 0.f;
+        if (tid == 0) {
+            const int q_next = q_more ? grab_group(q_raw) : n_groups;
+            q_more = q_next < n_groups;
+            qslot[slot] = q_next;
+        }
         __syncthreads();
+        const int grp_next = __builtin_amdgcn_readfirstlane(qslot[slot]);
         if (STAMP) { unsigned long long t = stamp_now(); t_w += t - ts; ts = t; }
-        if (grp + P.tile_parts < n_groups) fetch(grp + P.tile_parts, v);
+        if (grp_next < n_groups) fetch(grp_next, v);
+        if (DEFER) flush();      // after the loads: the compiler waits for everything outstanding before it reuses their registers
+        if (q_more) q_raw = grab_raw();      // likewise the next grab: issued here, looked at one iteration later
         if (STAMP) { unsigned long long t = stamp_now(); t_f += t - ts; ts = t; }
         if (w_ok) {
             int tile[T];
@@ -399,7 +451,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(TT == 
                 {
                     f32x4 e[T];
 #pragma unroll
-                    for (int t = 0; t < T; ++t) e[t] = apply_func(fk0, ex0, z[t]);
+                    for (int t = 0; t < T; ++t) e[t] = FSPEC == 1 ? z[t] : apply_func(fk0, ex0, z[t]);
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -408,7 +460,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(TT == 
                 {
                     f32x4 e[T];
 #pragma unroll
-                    for (int t = 0; t < T; ++t) e[t] = apply_func(fk1, ex1, z[t]);
+                    for (int t = 0; t < T; ++t) e[t] = FSPEC == 1 ? pow_abs4(z[t], ex1) : apply_func(fk1, ex1, z[t]);
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -451,7 +503,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(TT == 
             for (int fi = 0; fi < 2; ++fi) {        // z tile 0: full, branch-free
                 f32x4 e[T];
 #pragma unroll
-                for (int t = 0; t < T; ++t) e[t] = apply_func(fi == 0 ? qfk0 : qfk1, fi == 0 ? qex0 : qex1, z1[0][t]);
+                for (int t = 0; t < T; ++t)
+                    e[t] = FSPEC == 1 ? (fi == 0 ? z1[0][t] : pow_abs4(z1[0][t], qex1)) : apply_func(fi == 0 ? qfk0 : qfk1, fi == 0 ? qex0 : qex1, z1[0][t]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
 #pragma unroll
@@ -465,10 +518,11 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(TT == 
             }
 #pragma unroll
             for (int fi = 0; fi < 2; ++fi) {        // z tile 1: partial (runtime k-step count)
-                const int nk = (int)((Q.nk2p[1] >> (4 * fi)) & 15);
+                const int nk = (FSPEC == 1 && REM4) ? 1 : (int)((Q.nk2p[1] >> (4 * fi)) & 15);
                 f32x4 e[T];
 #pragma unroll
-                for (int t = 0; t < T; ++t) e[t] = apply_func(fi == 0 ? qfk0 : qfk1, fi == 0 ? qex0 : qex1, z1[1][t]);
+                for (int t = 0; t < T; ++t)
+                    e[t] = FSPEC == 1 ? (fi == 0 ? z1[1][t] : pow_abs4(z1[1][t], qex1)) : apply_func(fi == 0 ? qfk0 : qfk1, fi == 0 ? qex0 : qex1, z1[1][t]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (r < nk) {
@@ -485,14 +539,14 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(TT == 
 #pragma unroll
                 for (int t = 0; t < T; ++t) y1[1][t] += rem4_rows(d4[t], g);
             }
-            if (REM4 && Q.pack_base > 0) {     // packed remainder tiles (hg_fused_dev.hpp, StageParams::pack_base)
-                const int slot = __builtin_amdgcn_readfirstlane(Q.pack_slot[n1]);
+            if (REM4 && Q.pack_base > 0) {     // packed remainder tiles (hg_fused_dev.hpp, StageParams::pack_base): stored one iteration later
 #pragma unroll
-                for (int t = 0; t < T; ++t)
-                    if (tile[t] < P.n_tiles) {
-                        Q.out[((size_t)tile[t] * Q.nb_out + n1) * 64 + lane] = y1[0][t];
-                        ((float*)(Q.out + ((size_t)tile[t] * Q.nb_out + Q.pack_base + (slot >> 2)) * 64 + lane))[slot & 3] = y1[1][t][0];
-                    }
+                for (int t = 0; t < T; ++t) {
+                    st_y0[t] = y1[0][t];
+                    st_y1[t] = y1[1][t][0];
+                }
+                st_grp = grp;
+                if (!DEFER) flush();
             } else {
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
@@ -502,13 +556,17 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(TT == 
             }
             if (STAMP) { unsigned long long t = stamp_now(); t_l1 += t - ts; ts = t; ++n_it; }
         }
+        grp = grp_next;
     }
+    if (DEFER) flush();
     if (STAMP && lane == 0 && P.stamps) {
-        unsigned long long* o = P.stamps + ((size_t)blockIdx.x * 8 + wave) * 8;
+        unsigned long long* o = P.stamps + ((size_t)blockIdx.x * 8 + wave) * 12;
+        const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
         o[0] = t_w; o[1] = t_f; o[2] = t_l0; o[3] = t_l1;
         o[4] = stamp_now() - t_all0;
-        o[5] = __builtin_amdgcn_s_memrealtime() - rt0;
+        o[5] = rt1 - rt0;
         o[6] = (unsigned long long)n_it;
+        o[7] = rt_entry; o[8] = rt0; o[9] = rt1;
     }
 }
 
@@ -545,13 +603,19 @@ StageFn pick_stage0(int mt1, int mt2, int T, int x_dtype) {
 StageFn pick_stage0p(int x_dtype) {
     return x_dtype == HG_U8 ? (StageFn)k_stage0p<4, uint8_t> : x_dtype == HG_F32 ? (StageFn)k_stage0p<4, float> : (StageFn)k_stage0p<4, double>;
 }
-StageFn2 pick_stage01p(int x_dtype, bool stamp, bool rem4, int T) {
-    if (T == 1 && rem4 && x_dtype == HG_F32) return (StageFn2)k_stage01p<float, false, true, 1>;     // experiment: one tile per pass, four waves per SIMD
-    if (T == 4 && rem4 && x_dtype == HG_F32) return (StageFn2)k_stage01p<float, false, true, 4>;     // experiment: four tiles per pass, two waves per SIMD
+// Tiles per pass of the instantiation pick_stage01p returns (the host sizes LDS and the group count with it): the
+// compile-time-expansion form takes ONE tile per pass at four waves per SIMD (124 VGPRs; 146 us against 153 with two
+// tiles at three waves), the generic form two tiles at three waves (168 VGPRs).
+int stage01p_tiles(bool rem4, bool fspec) { return rem4 && fspec ? 1 : 2; }
+
+StageFn2 pick_stage01p(int x_dtype, bool stamp, bool rem4, bool fspec) {
     if (rem4) {
 #ifdef HIGSFA_DIAG
-        if (stamp && x_dtype == HG_F32) return (StageFn2)k_stage01p<float, true, true>;
+        if (stamp && x_dtype == HG_F32) return fspec ? (StageFn2)k_stage01p<float, true, true, 1, 1> : (StageFn2)k_stage01p<float, true, true>;
 #endif
+        if (fspec)
+            return x_dtype == HG_U8 ? (StageFn2)k_stage01p<uint8_t, false, true, 1, 1>
+                                    : x_dtype == HG_F32 ? (StageFn2)k_stage01p<float, false, true, 1, 1> : (StageFn2)k_stage01p<double, false, true, 1, 1>;
         return x_dtype == HG_U8 ? (StageFn2)k_stage01p<uint8_t, false, true>
                                 : x_dtype == HG_F32 ? (StageFn2)k_stage01p<float, false, true> : (StageFn2)k_stage01p<double, false, true>;
     }
