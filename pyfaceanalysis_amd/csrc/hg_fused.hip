@@ -47,6 +47,7 @@ struct FusedOptions {
     // match the per-layer kernels' throughput), so the default stops at 8 tiles.
     int chain_max_tiles = 8;
     bool no_pack = false;         // HIGSFA_NO_PACK: remainder tiles as whole blocks
+    bool no_direct = false;       // HIGSFA_NO_DIRECT: front kernel always stages the input rows through LDS (k_stage01p)
     bool no_fspec = false;        // HIGSFA_NO_FSPEC: front kernel without the compile-time (identity, abs-power) expansion
     int splitm_max_nodes = 4;     // experiments: HIGSFA_SPLITM_MAX
     int shape_variant = 0;        // experiments: HIGSFA_SHAPES
@@ -62,6 +63,7 @@ struct FusedOptions {
         if (const char* e = getenv("HIGSFA_CHAIN_MAX_TILES")) o.chain_max_tiles = std::max(0, atoi(e));
         o.no_pack = getenv("HIGSFA_NO_PACK") != nullptr;
         o.no_fspec = getenv("HIGSFA_NO_FSPEC") != nullptr;
+        o.no_direct = getenv("HIGSFA_NO_DIRECT") != nullptr;
         if (const char* e = getenv("HIGSFA_SPLITM_MAX")) o.splitm_max_nodes = atoi(e);
         if (const char* e = getenv("HIGSFA_SHAPES")) o.shape_variant = atoi(e);
         return o;
@@ -799,6 +801,8 @@ struct HostStage {
     std::vector<DRun> runs;
     std::vector<int32_t> piece_col, koff;
     std::vector<float> kmean;
+    std::vector<int32_t> kcol;     // k_stage01d: [node][g] first source column of the lane group's four (empty: not applicable)
+    bool direct_ok = false;
     int lds_stride = 0, max_chunk_nodes = 0, max_chunk_pieces = 0;
     int kind = 0;            // 0: affine-expansion-affine layer, 1: row-major -> fragment gather, 2: iGSFA layer, 3: table-driven expansion
     int neb = 0;             // kind 3: K-blocks of the expanded input
@@ -813,7 +817,7 @@ struct HostStage {
     DevBuf d_gcol;
     int64_t mfma_per_tile = 0;
     std::string name;
-    DevBuf d_afrag, d_bias, d_kb1tab, d_chunks, d_runs, d_piece, d_koff, d_kmean;
+    DevBuf d_afrag, d_bias, d_kb1tab, d_chunks, d_runs, d_piece, d_koff, d_kmean, d_kcol;
 };
 
 class FusedExecutor : public Executor {
@@ -1141,6 +1145,7 @@ public:
                 s.d_piece.upload(s.piece_col.data(), s.piece_col.size() * 4);
                 s.d_koff.upload(s.koff.data(), s.koff.size() * 4);
                 s.d_kmean.upload(s.kmean.data(), s.kmean.size() * 4);
+                if (!s.kcol.empty()) s.d_kcol.upload(s.kcol.data(), s.kcol.size() * 4);
             }
         }
         d_col_base_.upload(col_base_.data(), col_base_.size() * 4);
@@ -1288,6 +1293,7 @@ public:
                 P.piece_col = (const int2*)s.d_piece.p;
                 P.koff = (const int32_t*)s.d_koff.p;
                 P.kmean = (const float*)s.d_kmean.p;
+                P.kcol = (const int32_t*)s.d_kcol.p;
                 P.x = x;
                 P.ldx = ldx;
                 P.n_rows = n;
@@ -1313,10 +1319,13 @@ public:
                 if (fuse01_ && P.vec4 && n_tiles >= FT) {
                     // layers 0 and 1 in one persistent kernel; layer 1 writes where its own launch would
                     StageParams Q = base_params(stages_[1], nullptr, cur);
-                    StageFn2 fn = pick_stage01p(x_dtype, false, rem4, fspec);
+                    // every wave on its own (k_stage01d) where the input layout allows it, else the LDS-staged kernel
+                    const bool direct = fspec && s.direct_ok && stages_[1].pack_out && (int64_t)16 * ldx + 2048 < 0x7fffffffll && !opt_.no_direct;
+                    StageFn2 fn = direct ? pick_stage01d(x_dtype, false) : pick_stage01p(x_dtype, false, rem4, fspec);
                     const int thr01 = 64 * std::max(1, (s.max_chunk_nodes + 1) / 2);   // one wave per pair of layer-0 nodes
-                    // two tiles of T = 2 batch tiles + 10 vectors of 16 floats (means, biases) per wave
-                    const size_t lds2 = (size_t)(kDoubleBuffer01 ? 2 : 1) * FT * 16 * s.lds_stride * 4 + (size_t)(thr01 / 64) * 160 * 4 + 16;   // + tile-group queue slots
+                    // LDS: the tile buffers of FT batch tiles (k_stage01p only) + 10 vectors of 16 floats (means, biases) per wave
+                    const size_t lds2 = direct ? (size_t)(thr01 / 64) * 160 * 4
+                                               : (size_t)(kDoubleBuffer01 ? 2 : 1) * FT * 16 * s.lds_stride * 4 + (size_t)(thr01 / 64) * 160 * 4 + 16;   // + tile-group queue slots
                     const int groups2 = (n_tiles + FT - 1) / FT;
                     int occ = 1;
                     set_lds_limit((StageFn)fn, lds2);
@@ -1336,16 +1345,19 @@ public:
                     if (opt_.debug) fprintf(stderr, "[front] occ %d threads %d lds %zu chunks %d tile_parts %d\n", occ, thr01, lds2, P.n_chunks, P.tile_parts);
 #ifdef HIGSFA_DIAG
                     if (opt_.stamp_stage == 0 && x_dtype == HG_F32) {
-                        fn = pick_stage01p(HG_F32, true, rem4, fspec);
+                        fn = direct ? pick_stage01d(HG_F32, true) : pick_stage01p(HG_F32, true, rem4, fspec);
                         stamp_blocks_ = P.n_chunks * P.tile_parts;
                         stamp_buf_.alloc((size_t)stamp_blocks_ * 8 * 12 * 8);
                         HG_HIP(hipMemsetAsync(stamp_buf_.p, 0, stamp_buf_.bytes, st));
                         P.stamps = (unsigned long long*)stamp_buf_.p;
                     }
 #endif
-                    P.work_ctr = work_counters(P.n_chunks, st);
-                    P.work_base = work_base_;
-                    work_base_ += (uint32_t)groups2;      // what this launch adds to every counter (StageParams::work_ctr)
+                    {   // k_stage01p: one queue of tile groups per chunk; k_stage01d: one queue of tiles per layer-1 node
+                        WorkQueue& wq = direct ? wq_direct_ : wq_front_;
+                        P.work_ctr = work_counters(wq, direct ? stages_[1].n_nodes : P.n_chunks, st);
+                        P.work_base = wq.base;
+                        wq.base += (uint32_t)groups2;      // what this launch adds to every counter (StageParams::work_ctr)
+                    }
                     hipLaunchKernelGGL(fn, (unsigned)(P.n_chunks * P.tile_parts), thr01, lds2, st, P, Q);
                     if (P.stamps) {
                         HG_HIP(hipStreamSynchronize(st));
@@ -1530,11 +1542,12 @@ public:
         bufB_.free();
         chain_buf_.free();
         chain_flags_.free();
-        work_ctr_.free();
+        wq_front_.ctr.free();
+        wq_direct_.ctr.free();
         d_col_base_.free();
         for (auto& s : stages_) {
             s.d_afrag.free(); s.d_bias.free(); s.d_kb1tab.free(); s.d_chunks.free();
-            s.d_runs.free(); s.d_piece.free(); s.d_koff.free(); s.d_kmean.free(); s.d_gcol.free(); s.d_etab.free(); s.d_pack_slot.free();
+            s.d_runs.free(); s.d_piece.free(); s.d_koff.free(); s.d_kmean.free(); s.d_kcol.free(); s.d_gcol.free(); s.d_etab.free(); s.d_pack_slot.free();
         }
         cap_rows_ = 0;
     }
@@ -1552,15 +1565,20 @@ private:
         return nb;
     }
 
-    // Counters of the dynamic tile-group queues (16 words apart); zeroed once, then only ever advanced (work_base_).
-    uint32_t* work_counters(int n_chunks, hipStream_t st) {
-        const size_t need = (size_t)n_chunks * 64;
-        if (work_ctr_.bytes < need) {
-            work_ctr_.alloc(std::max<size_t>(need, 64 * 1024));
-            HG_HIP(hipMemsetAsync(work_ctr_.p, 0, work_ctr_.bytes, st));
-            work_base_ = 0;
+    // Counters of the dynamic tile queues (16 words apart); zeroed once, then only ever advanced.  One set per kernel that
+    // uses them (every launch advances all of ITS counters by the same amount).
+    struct WorkQueue {
+        DevBuf ctr;
+        uint32_t base = 0;
+    };
+    uint32_t* work_counters(WorkQueue& q, int n, hipStream_t st) {
+        const size_t need = (size_t)n * 64;
+        if (q.ctr.bytes < need) {
+            q.ctr.alloc(std::max<size_t>(need, 64 * 1024));
+            HG_HIP(hipMemsetAsync(q.ctr.p, 0, q.ctr.bytes, st));
+            q.base = 0;
         }
-        return (uint32_t*)work_ctr_.p;
+        return (uint32_t*)q.ctr.p;
     }
 
     void set_lds_limit(StageFn fn, size_t bytes) {
@@ -1689,6 +1707,22 @@ private:
         }
         hs.contig4 = contig;
         hs.vec_ok = vec_ok;
+        // k_stage01d: every lane group of every node reads four contiguous, 16-byte aligned source columns
+        bool direct = contig && vec_ok && s0_transpose_ && kb1 == 1;
+        hs.kcol.assign((size_t)n * 4, 0);
+        for (int k = 0; k < n && direct; ++k) {
+            const FNode& nd = st.nodes[k];
+            if (nd.in_dim != 16) { direct = false; break; }
+            for (int g = 0; g < 4; ++g) {
+                const int c0 = s0_pos(0, g), col = st.conn[nd.in_off + c0];
+                for (int r = 0; r < 4; ++r)
+                    if (s0_pos(r, g) != c0 + r || st.conn[nd.in_off + c0 + r] != col + r) direct = false;
+                if (col % 4) direct = false;
+                hs.kcol[(size_t)k * 4 + g] = col;
+            }
+        }
+        hs.direct_ok = direct;
+        if (!direct) hs.kcol.clear();
     }
 
     // First layer of iGSFA nodes: a gather pseudo-stage turns the row-major input into fragment-order
@@ -2277,8 +2311,8 @@ private:
     bool s0_transpose_ = false, fuse01_ = false;
     std::vector<HostStage> stages_;
     std::vector<int32_t> col_base_;
-    DevBuf d_col_base_, bufA_, bufB_, stamp_buf_, work_ctr_;
-    uint32_t work_base_ = 0;
+    DevBuf d_col_base_, bufA_, bufB_, stamp_buf_;
+    WorkQueue wq_front_, wq_direct_;
     int stamp_blocks_ = 0;
     std::map<const void*, size_t> lds_set_;
     std::map<std::tuple<const void*, int, size_t>, int> occ_;

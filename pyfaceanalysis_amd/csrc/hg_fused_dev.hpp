@@ -50,6 +50,7 @@ struct StageParams {
     const int2* piece_col;     // per chunk piece (4 columns) -> {first source column, LDS word offset}
     const int32_t* koff;       // [node*kb1 + kb][g][r] LDS word offsets
     const float* kmean;        // same shape: means subtracted by the loader
+    const int32_t* kcol;       // k_stage01d: [node][g] first of the four contiguous source columns of lane group g
     const void* x;
     int64_t ldx, n_rows;
     int32_t lds_stride, nk_last, vec4, contig4;
@@ -310,6 +311,7 @@ StageFn pick_stage0(int mt1, int mt2, int T, int x_dtype);            // hg_fuse
 StageFn pick_stage0p(int x_dtype);
 StageFn2 pick_stage01p(int x_dtype, bool stamp, bool rem4, bool fspec);
 int stage01p_tiles(bool rem4, bool fspec);
+StageFn2 pick_stage01d(int x_dtype, bool stamp);       // every wave on its own, no LDS tile (hg_fused_front.hip)
 StageFn pick_igsfa(int ms, int mo, int T, int kb1);                   // hg_fused_igsfa.hip
 StageFn pick_igfold(int mo, int T);
 StageFn pick_prod(int mt1, int mt2, int T);                           // hg_fused_prod.hip
@@ -319,8 +321,14 @@ void launch_im2frag(const void* x, int x_dtype, int64_t ldx, int64_t n_rows, int
 
 // 4 consecutive input elements -> 4 floats (16-byte / 4-byte / 32-byte loads)
 template <typename XT> struct Vec4Load;
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+constexpr int kBufferFlags = 0x00020000;      // raw buffer, 32-bit data format (as hg_fused_chain.hip)
 template <> struct Vec4Load<float> {
     static __device__ __forceinline__ f32x4 ld(const float* p) { return *(const f32x4*)p; }
+    // same through a buffer resource: scalar base, 32-bit byte offset per lane, out-of-range reads return 0
+    static __device__ __forceinline__ f32x4 buf(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+    }
 };
 template <> struct Vec4Load<uint8_t> {
     static __device__ __forceinline__ f32x4 ld(const uint8_t* p) {
@@ -331,6 +339,10 @@ template <> struct Vec4Load<uint8_t> {
         v[2] = (float)((w >> 16) & 0xff);
         v[3] = (float)(w >> 24);
         return v;
+    }
+    static __device__ __forceinline__ f32x4 buf(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+        const uint32_t w = __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0);
+        return f32x4{(float)(w & 0xff), (float)((w >> 8) & 0xff), (float)((w >> 16) & 0xff), (float)(w >> 24)};
     }
 };
 template <> struct Vec4Load<double> {
@@ -343,6 +355,12 @@ template <> struct Vec4Load<double> {
         v[2] = (float)b[0];
         v[3] = (float)b[1];
         return v;
+    }
+    static __device__ __forceinline__ f32x4 buf(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+        typedef double f64x2 __attribute__((ext_vector_type(2)));
+        const f64x2 a = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+        const f64x2 b = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(r, off + 16, 0, 0));
+        return f32x4{(float)a[0], (float)a[1], (float)b[0], (float)b[1]};
     }
 };
 

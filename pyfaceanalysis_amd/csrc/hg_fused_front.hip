@@ -570,6 +570,228 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(TT == 
     }
 }
 
+// Stages 0 AND 1, every wave on its own ("direct" form of k_stage01p for the case its compile-time instantiation covers:
+// contiguous 4-column pieces, both layers expanding with (identity, |x|^p), layer-1 remainder tiles in 4x4 form).
+// A wave owns layer-1 node w of its chunk and the two layer-0 children; lane (g, j) loads the four contiguous input
+// columns of lane group g of sub-image j straight from the caller's matrix into the MFMA B operand — 16 bytes per lane,
+// the eight loads that share a 128-byte line (two children x four waves of the workgroup) are issued within one
+// iteration of each other and meet in L1 / L2 — so there is no LDS tile, no cooperative index arithmetic and NO BARRIER:
+// in k_stage01p every tile group ends with the four waves of a workgroup (four SIMDs, each with its own mix of
+// co-resident waves) waiting for the slowest.  One batch tile per pass; tiles are handed out per wave from the queue of
+// its layer-1 node (StageParams::work_ctr, counter index = layer-1 node); loads, deferred stores and the next grab are
+// issued together right after the previous iteration's data has been taken over, and are looked at one iteration later.
+// 100 VGPRs at four waves per SIMD (five waves: 96 VGPRs with spills, 170 us against 141).
+template <typename XT, bool STAMP = false>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) k_stage01d(StageParams P, StageParams Q) {
+    extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
+    unsigned long long rt_entry = 0;
+    if (STAMP) rt_entry = __builtin_amdgcn_s_memrealtime();
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, j = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ci = blockIdx.x % P.n_chunks, part = blockIdx.x / P.n_chunks;
+    const DChunk ck = P.chunks[ci];
+    if (2 * wave + 1 >= ck.node_count) return;         // chunks hold whole pairs; no barrier below
+    const XT* x = (const XT*)P.x;
+    float* cst = (float*)smem + wave * 160;            // this wave's means and biases (10 vectors of 16 floats): read back every tile
+    enum { C_MU = 0, C_B1 = 2, C_B2 = 4, C_QB1 = 6, C_QB2 = 8 };
+    uint32_t src[2];          // byte offset of this lane's four columns inside a batch tile's rows
+    f32x4 w_a1[2], w_a2[2][2];
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+        const int ni = ck.node_begin + 2 * wave + sl;
+        const size_t ent = (size_t)ni * 16 + g * 4;
+        src[sl] = (uint32_t)(j * (int)P.ldx + P.kcol[ni * 4 + g]) * (uint32_t)sizeof(XT);
+        if (j == 0) *(f32x4*)(cst + (C_MU + sl) * 16 + g * 4) = *(const f32x4*)(P.kmean + ent);
+        const f32x4* wp = P.afrag + (size_t)ni * P.node_blocks * 64 + lane;
+        w_a1[sl] = wp[0];
+        w_a2[sl][0] = wp[64];
+        w_a2[sl][1] = wp[128];
+        const float* bp = P.bias + (size_t)ni * P.bias_floats + g * 4;
+        if (j == 0) {
+            *(f32x4*)(cst + (C_B1 + sl) * 16 + g * 4) = *(const f32x4*)bp;
+            *(f32x4*)(cst + (C_B2 + sl) * 16 + g * 4) = *(const f32x4*)(bp + 16);
+        }
+    }
+    const int n1 = (ck.node_begin >> 1) + wave;
+    // layer-1 weights: first affine [kb][mt]; second affine, first z tile [fi][mt]; of the second z tile (four real rows = ONE
+    // k-step) only that k-step's value per lane is kept
+    f32x4 q_a1[2][2], q_a2[2][2];
+    float q_a2t[2][2];
+    {
+        const f32x4* wq = Q.afrag + (size_t)n1 * Q.node_blocks * 64 + lane;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) q_a1[kb][mt] = wq[(kb * 2 + mt) * 64];
+        const f32x4* wq2 = wq + Q.kb1 * 2 * 64;
+#pragma unroll
+        for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                q_a2[fi][mt] = wq2[(fi * 2 + mt) * 64];
+                q_a2t[fi][mt] = wq2[((2 + fi) * 2 + mt) * 64][0];
+            }
+        const float* bq = Q.bias + (size_t)n1 * Q.bias_floats + g * 4;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+            if (j == 0) {
+                *(f32x4*)(cst + (C_QB1 + mt) * 16 + g * 4) = *(const f32x4*)(bq + mt * 16);
+                *(f32x4*)(cst + (C_QB2 + mt) * 16 + g * 4) = *(const f32x4*)(bq + 32 + mt * 16);
+            }
+    }
+    if (!Q.a4x4) {       // 4x4 form of the second-tile fragments (see k_stage01p)
+        const int bsrc = ((lane & 48) | ((lane & 3) << 2)) << 2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+                q_a1[kb][1][r] = __int_as_float(__builtin_amdgcn_ds_bpermute(bsrc, __float_as_int(q_a1[kb][1][r])));
+#pragma unroll
+            for (int fi = 0; fi < 2; ++fi)
+                q_a2[fi][1][r] = __int_as_float(__builtin_amdgcn_ds_bpermute(bsrc, __float_as_int(q_a2[fi][1][r])));
+        }
+#pragma unroll
+        for (int fi = 0; fi < 2; ++fi) q_a2t[fi][1] = __int_as_float(__builtin_amdgcn_ds_bpermute(bsrc, __float_as_int(q_a2t[fi][1])));
+    }
+    const float ex1 = P.expo[1], qex1 = Q.expo[1];
+    const int n_tiles = P.n_tiles;
+    const int64_t tile_step = (int64_t)16 * P.ldx;
+
+    // Loads and stores go through buffer resources rebuilt per tile (scalar base + one 32-bit offset per lane, no 64-bit
+    // address arithmetic in vector registers); rows past the end of the batch are out of range and read as zero.
+    const uint32_t row_bytes = (uint32_t)P.ldx * (uint32_t)sizeof(XT);
+    auto fetch = [&](int tile, f32x4 (&v)[2]) {
+        const int64_t rows = P.n_rows - (int64_t)tile * 16;
+        const __amdgpu_buffer_rsrc_t r =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(x + tile * tile_step), 0, (int)((rows < 16 ? (uint32_t)rows : 16u) * row_bytes), kBufferFlags);
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) v[sl] = Vec4Load<XT>::buf(r, src[sl]);
+    };
+    // tile queue of this layer-1 node: first tile = part, then tile_parts + (counter - base); lane 0 grabs
+    uint32_t* qctr = P.work_ctr + (size_t)n1 * 16;
+    const uint32_t q_dyn = (uint32_t)(n_tiles - P.tile_parts);
+    auto grab_raw = [&]() -> uint32_t { return __builtin_amdgcn_atomic_inc32(qctr, 0xffffffffu, __ATOMIC_RELAXED, "agent"); };
+    uint32_t q_raw = 0;
+    bool q_more = true;          // wave-uniform: no grab has failed yet
+    if (lane == 0) q_raw = grab_raw();
+    f32x4 v[2];
+    int tile = part;
+    if (tile < n_tiles) fetch(tile, v);
+    // deferred stores (see k_stage01p)
+    // (the host only picks this kernel for a layer 1 that writes packed remainder tiles: Q.pack_base > 0)
+    f32x4 st_y0;
+    float st_y1 = 0.f;
+    int st_tile = -1;
+    const int pk_slot = __builtin_amdgcn_readfirstlane(Q.pack_slot[n1]);
+    const uint32_t pk_off = (uint32_t)(Q.pack_base + (pk_slot >> 2)) * 1024u + (uint32_t)(pk_slot & 3) * 4u;
+    const uint32_t out_tile_bytes = (uint32_t)Q.nb_out * 1024u;
+    auto flush = [&]() {
+        if (st_tile < 0) return;
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(Q.out + (size_t)st_tile * Q.nb_out * 64), 0, (int)out_tile_bytes, kBufferFlags);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, st_y0), r, (uint32_t)lane * 16u, (uint32_t)n1 * 1024u, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(st_y1), r, (uint32_t)lane * 16u, pk_off, 0);
+        st_tile = -1;
+    };
+    unsigned long long t_top = 0, t_l0 = 0, t_l1 = 0, t_all0 = 0, rt0 = 0, ts = 0;
+    int n_it = 0;
+    if (STAMP) {
+        t_all0 = stamp_now();
+        rt0 = __builtin_amdgcn_s_memrealtime();
+    }
+    while (tile < n_tiles) {
+        // keeps the compiler from hoisting the ten constant vectors out of the loop (40 VGPRs: spills at four waves per SIMD);
+        // they are meant to be re-read from LDS every tile
+        asm volatile("" ::: "memory");
+        if (STAMP) ts = stamp_now();
+        int next = n_tiles;
+        if (q_more) {
+            const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)q_raw) - P.work_base;
+            next = k < q_dyn ? (int)(P.tile_parts + k) : n_tiles;
+            q_more = next < n_tiles;
+        }
+        // ---- layer 0, first affine of both children; the sub-image registers are free after it, so the next tile's loads
+        // (and with them the deferred stores and the next grab) go out here
+        f32x4 z0[2];
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            const f32x4 bf = v[sl] - *(const f32x4*)(cst + (C_MU + sl) * 16 + g * 4);
+            z0[sl] = *(const f32x4*)(cst + (C_B1 + sl) * 16 + g * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z0[sl] = MFMA16(w_a1[sl][r], bf[r], z0[sl]);
+        }
+        if (next < n_tiles) fetch(next, v);
+        flush();
+        if (q_more && lane == 0) q_raw = grab_raw();
+        if (STAMP) { unsigned long long t = stamp_now(); t_top += t - ts; ts = t; }
+        f32x4 y0[2];
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            y0[sl] = *(const f32x4*)(cst + (C_B2 + sl) * 16 + g * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y0[sl] = MFMA16(w_a2[sl][0][r], z0[sl][r], y0[sl]);
+            const f32x4 e = pow_abs4(z0[sl], ex1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y0[sl] = MFMA16(w_a2[sl][1][r], e[r], y0[sl]);
+        }
+        if (STAMP) { unsigned long long t = stamp_now(); t_l0 += t - ts; ts = t; }
+        // ---- layer 1
+        f32x4 z1[2], y1[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            z1[mt] = *(const f32x4*)(cst + (C_QB1 + mt) * 16 + g * 4);
+            y1[mt] = *(const f32x4*)(cst + (C_QB2 + mt) * 16 + g * 4);
+        }
+        f32x4 d4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                z1[0] = MFMA16(q_a1[kb][0][r], y0[kb][r], z1[0]);
+                d4 = MFMA4(q_a1[kb][1][r], y0[kb][r], d4);
+            }
+        z1[1] += rem4_rows(d4, g);
+        d4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int fi = 0; fi < 2; ++fi) {
+            const f32x4 e = fi == 0 ? z1[0] : pow_abs4(z1[0], qex1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                y1[0] = MFMA16(q_a2[fi][0][r], e[r], y1[0]);
+                d4 = MFMA4(q_a2[fi][1][r], e[r], d4);
+            }
+        }
+#pragma unroll
+        for (int fi = 0; fi < 2; ++fi) {        // second z tile: four real rows = one k-step
+            const float e0 = fi == 0 ? z1[1][0] : pow_abs(z1[1][0], qex1);
+            y1[0] = MFMA16(q_a2t[fi][0], e0, y1[0]);
+            d4 = MFMA4(q_a2t[fi][1], e0, d4);
+        }
+        y1[1] += rem4_rows(d4, g);
+        st_y0 = y1[0];
+        st_y1 = y1[1][0];
+        st_tile = tile;
+        if (STAMP) { unsigned long long t = stamp_now(); t_l1 += t - ts; ts = t; ++n_it; }
+        tile = next;
+    }
+    flush();
+    if (STAMP && lane == 0 && P.stamps) {
+        unsigned long long* o = P.stamps + ((size_t)blockIdx.x * 8 + wave) * 12;
+        const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
+        o[0] = t_top; o[1] = 0; o[2] = t_l0; o[3] = t_l1;
+        o[4] = stamp_now() - t_all0;
+        o[5] = rt1 - rt0;
+        o[6] = (unsigned long long)n_it;
+        o[7] = rt_entry; o[8] = rt0; o[9] = rt1;
+    }
+}
+
+StageFn2 pick_stage01d(int x_dtype, bool stamp) {
+#ifdef HIGSFA_DIAG
+    if (stamp && x_dtype == HG_F32) return (StageFn2)k_stage01d<float, true>;
+#endif
+    return x_dtype == HG_U8 ? (StageFn2)k_stage01d<uint8_t> : x_dtype == HG_F32 ? (StageFn2)k_stage01d<float> : (StageFn2)k_stage01d<double>;
+}
+
 template <int MT1, int MT2, typename XT>
 static StageFn pick_stage0_t(int T) {
     if (T == 4) return k_stage0<MT1, MT2, 4, XT>;
