@@ -505,6 +505,8 @@ __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
                     f32x4 d4[T];
 #pragma unroll
                     for (int t = 0; t < T; ++t) d4[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    unsigned long long ts0 = 0, ts1 = 0;
+                    if (STAMP) ts0 = stamp_now();
 #pragma unroll
                     for (int kbi = 0; kbi < KBF; ++kbi) {
                         const int nkr = __builtin_amdgcn_readfirstlane(kt[kbi].y), nk = nkr & 255, r0 = nkr >> 8;
@@ -525,7 +527,14 @@ __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
                             for (int t = 0; t < T; ++t) bq[kbi][t] = P.in[(size_t)((in_group ? trow[t] : trow_nx[t]) + sbn) * 64 + lane];
                         }
                     }
+                    if (STAMP) ts1 = stamp_now();
                     node_tail<MT1, MT2, T, REM>(P, wA2, b1 + MT1 * 16, g0 + ln, z, tile, lane);
+                    if (STAMP) {
+                        unsigned long long ts2 = stamp_now();
+                        t_g1 += ts1 - ts0;
+                        t_tail += ts2 - ts1;
+                        ++n_it;
+                    }
                 }
                 if (!has_next) break;
 #pragma unroll
@@ -1486,9 +1495,10 @@ public:
                 size_t lds_bytes = (size_t)npg * s.node_blocks * 1024 + (size_t)npg * s.bias_floats * 4 + (size_t)npg * s.kb1 * 8;
                 StageFn fn = pick_stage(s.mt1, s.mt2, T, s.rem4, kbf);
 #ifdef HIGSFA_DIAG
-                if (opt_.stamp_stage == (int)si && s.mt1 == s.mt2 && (s.mt1 == 4 || s.mt1 == 3) && T == 2 && !s.rem4 && kbf == 0) {
+                const bool stamp_kbf3 = s.mt1 == 3 && s.mt2 == 3 && T == 2 && s.rem4 && kbf == 3;
+                if (opt_.stamp_stage == (int)si && (stamp_kbf3 || (s.mt1 == s.mt2 && (s.mt1 == 4 || s.mt1 == 3) && T == 2 && !s.rem4 && kbf == 0))) {
                     // diagnostic instantiation with s_memtime stamps (never used in timed runs)
-                    fn = s.mt1 == 4 ? (StageFn)k_stage<4, 4, 2, true> : (StageFn)k_stage<3, 3, 2, true>;
+                    fn = stamp_kbf3 ? (StageFn)k_stage<3, 3, 2, true, true, 3> : s.mt1 == 4 ? (StageFn)k_stage<4, 4, 2, true> : (StageFn)k_stage<3, 3, 2, true>;
                     stamp_buf_.alloc((size_t)blocks * 8 * 8 * 8);
                     HG_HIP(hipMemsetAsync(stamp_buf_.p, 0, stamp_buf_.bytes, st));
                     P.stamps = (unsigned long long*)stamp_buf_.p;

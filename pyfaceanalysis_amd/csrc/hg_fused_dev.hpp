@@ -132,14 +132,14 @@ __device__ __forceinline__ f32x4 apply_func_uniform(int func, float expo, f32x4 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 // One K-block: acc[mt][t] += A[mt] (16 x 16, four k-steps) * B[t].  `wp` points at the block's first
-// A fragment (+lane); fragments of consecutive m-tiles are 64 f32x4 apart.  With T >= 2 the A
-// fragment is read one m-tile at a time (4 live registers instead of 4*MT): consecutive MFMAs then
-// alternate between T accumulators, which is enough to cover the 40-cycle dependent latency of
-// v_mfma_f32_16x16x4_f32.  With T == 1 all m-tiles are interleaved instead.
+// A fragment (+lane); fragments of consecutive m-tiles are 64 f32x4 apart.
 // k-steps r0 .. nk-1 of the block are multiplied (r0 > 0: a packed remainder block, whose leading k-steps belong to other nodes).
 template <int MT, int T, typename WP>
 __device__ __forceinline__ void gemm_block(WP wp, const f32x4 (&b)[T], f32x4 (&acc)[MT][T], int nk, int r0 = 0) {
-    if constexpr (T >= 2) {
+    if constexpr (MT >= 4 && T >= 2) {
+        // m-tile outer: one A fragment live (4 registers instead of 16).  In isolation this order is the slower one (a branch
+        // and an exposed LDS read per pair of MFMAs: 88 % of the MFMA peak against 96 %, tools/ubench/mfma_loop.hip V5 / V4),
+        // but inside k_stage<4,4,2> — 116 VGPRs this way, 127 the other — it measures 3-6 % FASTER on layers 3-5.
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const f32x4 a = wp[mt * 64];
@@ -151,6 +151,8 @@ __device__ __forceinline__ void gemm_block(WP wp, const f32x4 (&b)[T], f32x4 (&a
                 }
         }
     } else {
+        // k-step outer, m-tile inner: ONE branch per k-step and MT x T MFMAs behind it, all A fragments of the block read
+        // from LDS up front (layer 2: 112 -> 105 us)
         f32x4 a[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) a[mt] = wp[mt * 64];
@@ -196,19 +198,19 @@ __device__ __forceinline__ f32x4 rem4_rows(f32x4 d, int g) {
 // gemm_block with the last m-tile in 4x4 form: tiles 0 .. MT-2 accumulate in acc, the last one in d4.
 template <int MT, int T, typename WP>
 __device__ __forceinline__ void gemm_block_rem(WP wp, const f32x4 (&b)[T], f32x4 (&acc)[MT][T], f32x4 (&d4)[T], int nk, int r0 = 0) {
+    f32x4 a[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const f32x4 a = wp[mt * 64];
+    for (int mt = 0; mt < MT; ++mt) a[mt] = wp[mt * 64];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (r >= r0 && r < nk) {
+    for (int r = 0; r < 4; ++r)
+        if (r >= r0 && r < nk) {
 #pragma unroll
-                for (int t = 0; t < T; ++t) {
-                    if (mt < MT - 1) acc[mt][t] = MFMA16(a[r], b[t][r], acc[mt][t]);
-                    else d4[t] = MFMA4(a[r], b[t][r], d4[t]);
-                }
-            }
-    }
+            for (int mt = 0; mt < MT - 1; ++mt)
+#pragma unroll
+                for (int t = 0; t < T; ++t) acc[mt][t] = MFMA16(a[mt][r], b[t][r], acc[mt][t]);
+#pragma unroll
+            for (int t = 0; t < T; ++t) d4[t] = MFMA4(a[MT - 1][r], b[t][r], d4[t]);
+        }
 }
 
 // Second half of a node: expansion of the z accumulators in registers, second affine, store.

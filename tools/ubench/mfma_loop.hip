@@ -36,6 +36,21 @@ __global__ void __launch_bounds__(512) k(const f32x4* __restrict__ w, const int2
             const int kn = (it + 1) & 15;
             for (int m = 0; m < 4; ++m) an[m] = wl[(kn * 4 + m) * 64];
         }
+        if (V == 5) {      // the order gemm_block used until round 2: m-tile outer (one A fragment live), k-step inner
+            int2 e = st[kb];
+            nk = __builtin_amdgcn_readfirstlane(e.y);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const f32x4 am = wl[(kb * 4 + m) * 64];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (r >= nk) continue;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) acc[m][t] = MFMA16(am[r], bf[t][r], acc[m][t]);
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             if ((V == 3 || V == 4) && r >= nk) continue;
@@ -84,6 +99,7 @@ int main(int argc, char** argv) {
         run<2>("V2 + A frags from LDS (prefetched)", w, tab, out, thr, per);
         run<3>("V3 V1 + nk branches", w, tab, out, thr, per);
         run<4>("V4 V3 + LDS table/readfirstlane", w, tab, out, thr, per);
+        run<5>("V5 V4 with m-tile outer, k-step inner", w, tab, out, thr, per);
     }
     return 0;
 }
