@@ -413,6 +413,11 @@ bool build_stages(const TNode& root, std::vector<FStage>& stages, std::string& w
 // before the second half of the previous node, whose MFMAs (no global loads of their own) cover the L2 / HBM round trip.
 // For small nodes (layer 2: four blocks of <= 4 k-steps) the one-block-ahead stream leaves each wave waiting ~1.5k cycles
 // per block (in-kernel stamps: GEMM 1 took 6x its MFMA time); costs KBF * T * 4 registers.
+#ifdef HIGSFA_DIAG
+#define HG_HOT(blk) ((P.whatif & 1) ? ((blk) & 1) : (blk))      // timing experiment: all input blocks from the first two of the tile row
+#else
+#define HG_HOT(blk) (blk)
+#endif
 template <int MT1, int MT2, int T, bool STAMP = false, bool REM = false, int KBF = 0>
 __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
     extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
@@ -478,7 +483,7 @@ __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
             f32x4 bq[KBF][T];
 #pragma unroll
             for (int kbi = 0; kbi < KBF; ++kbi) {
-                const int sb0 = __builtin_amdgcn_readfirstlane(stab[kbi].x);
+                const int sb0 = HG_HOT(__builtin_amdgcn_readfirstlane(stab[kbi].x));
 #pragma unroll
                 for (int t = 0; t < T; ++t) bq[kbi][t] = P.in[(size_t)(trow[t] + sb0) * 64 + lane];
             }
@@ -522,7 +527,7 @@ __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
                         const int2* ktn = in_group ? kt + KBF : stab;
 #pragma unroll
                         for (int kbi = 0; kbi < KBF; ++kbi) {
-                            const int sbn = __builtin_amdgcn_readfirstlane(ktn[kbi].x);
+                            const int sbn = HG_HOT(__builtin_amdgcn_readfirstlane(ktn[kbi].x));
 #pragma unroll
                             for (int t = 0; t < T; ++t) bq[kbi][t] = P.in[(size_t)((in_group ? trow[t] : trow_nx[t]) + sbn) * 64 + lane];
                         }
@@ -549,7 +554,7 @@ __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
         int nk;
         {
             const int2 kb = stab[0];
-            const int sb0 = __builtin_amdgcn_readfirstlane(kb.x);
+            const int sb0 = HG_HOT(__builtin_amdgcn_readfirstlane(kb.x));
             nk = __builtin_amdgcn_readfirstlane(kb.y);
 #pragma unroll
             for (int t = 0; t < T; ++t) bf[t] = P.in[(size_t)(trow[t] + sb0) * 64 + lane];
@@ -584,7 +589,7 @@ __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
                     const bool in_node = kbi + 1 < P.kb1;
                     const bool in_group = in_node || ln + 1 < gn;
                     const int2 kbn = in_node ? kt[kbi + 1] : (ln + 1 < gn ? kt[P.kb1] : stab[0]);
-                    const int sbn = __builtin_amdgcn_readfirstlane(kbn.x);
+                    const int sbn = HG_HOT(__builtin_amdgcn_readfirstlane(kbn.x));
                     const int nkn = __builtin_amdgcn_readfirstlane(kbn.y);
 #pragma unroll
                     for (int t = 0; t < T; ++t) bfn[t] = P.in[(size_t)((in_group ? trow[t] : trow_nx[t]) + sbn) * 64 + lane];
@@ -1506,6 +1511,9 @@ public:
                 }
 #endif
                 set_lds_limit(fn, lds_bytes);
+#ifdef HIGSFA_DIAG
+                if (const char* e = getenv("HIGSFA_WHATIF")) P.whatif = atoi(e);
+#endif
                 hipLaunchKernelGGL(fn, (unsigned)blocks, nw * 64, lds_bytes, st, P);
                 if (P.stamps) {
                     HG_HIP(hipStreamSynchronize(st));

@@ -75,6 +75,8 @@ struct StageParams {
     // split the first workgroup of a CU finishes 25 % before the third and the kernel ends with a third of its waves.
     uint32_t* work_ctr;
     uint32_t work_base;
+    int32_t whatif;     // diagnostic build only (HIGSFA_WHATIF): bit 0 = k_stage reads every input block from the tile's first block (cache-hot),
+                        // bit 1 = node_tail stores nothing — timing experiments, results are wrong
 };
 
 __device__ __forceinline__ unsigned long long stamp_now() {
@@ -221,6 +223,11 @@ __device__ __forceinline__ void node_tail(const StageParams& P, WP wA2, BP b2, i
                                           const int (&tile)[T], int lane) {
     const int g = lane >> 4;
     const int out_blk = node * P.mto;
+#ifdef HIGSFA_DIAG
+    const bool no_store = (P.whatif & 2) != 0;
+#else
+    constexpr bool no_store = false;
+#endif
     if (!P.has_exp) {
 #pragma unroll
         for (int mt = 0; mt < MT1; ++mt)
@@ -265,11 +272,11 @@ __device__ __forceinline__ void node_tail(const StageParams& P, WP wA2, BP b2, i
             for (int mt = 0; mt < MT2 - 1; ++mt)
 #pragma unroll
                 for (int t = 0; t < T; ++t)
-                    if (tile[t] < P.n_tiles) P.out[((size_t)tile[t] * P.nb_out + node * (MT2 - 1) + mt) * 64 + lane] = y[mt][t];
+                    if (tile[t] < P.n_tiles && !no_store) P.out[((size_t)tile[t] * P.nb_out + node * (MT2 - 1) + mt) * 64 + lane] = y[mt][t];
             const int slot = __builtin_amdgcn_readfirstlane(P.pack_slot[node]);
 #pragma unroll
             for (int t = 0; t < T; ++t)
-                if (tile[t] < P.n_tiles)
+                if (tile[t] < P.n_tiles && !no_store)
                     ((float*)(P.out + ((size_t)tile[t] * P.nb_out + P.pack_base + (slot >> 2)) * 64 + lane))[slot & 3] = y[MT2 - 1][t][0];
             return;
         }
@@ -278,7 +285,7 @@ __device__ __forceinline__ void node_tail(const StageParams& P, WP wA2, BP b2, i
     for (int mt = 0; mt < MT2; ++mt)
 #pragma unroll
         for (int t = 0; t < T; ++t)
-            if (tile[t] < P.n_tiles) P.out[((size_t)tile[t] * P.nb_out + out_blk + mt) * 64 + lane] = y[mt][t];
+            if (tile[t] < P.n_tiles && !no_store) P.out[((size_t)tile[t] * P.nb_out + out_blk + mt) * 64 + lane] = y[mt][t];
 }
 
 
