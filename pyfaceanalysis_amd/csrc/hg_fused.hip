@@ -1372,6 +1372,9 @@ public:
                         P.work_base = wq.base;
                         wq.base += (uint32_t)groups2;      // what this launch adds to every counter (StageParams::work_ctr)
                     }
+#ifdef HIGSFA_DIAG
+                    if (const char* e = getenv("HIGSFA_WHATIF")) P.whatif = atoi(e);
+#endif
                     hipLaunchKernelGGL(fn, (unsigned)(P.n_chunks * P.tile_parts), thr01, lds2, st, P, Q);
                     if (P.stamps) {
                         HG_HIP(hipStreamSynchronize(st));

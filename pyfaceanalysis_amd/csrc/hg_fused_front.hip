@@ -661,6 +661,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     // address arithmetic in vector registers); rows past the end of the batch are out of range and read as zero.
     const uint32_t row_bytes = (uint32_t)P.ldx * (uint32_t)sizeof(XT);
     auto fetch = [&](int tile, f32x4 (&v)[2]) {
+#ifdef HIGSFA_DIAG
+        if (P.whatif & 1) tile = part;          // timing experiment: every pass reads the wave's first tile again (cache-hot)
+#endif
         const int64_t rows = P.n_rows - (int64_t)tile * 16;
         const __amdgpu_buffer_rsrc_t r =
             __builtin_amdgcn_make_buffer_rsrc((void*)(x + tile * tile_step), 0, (int)((rows < 16 ? (uint32_t)rows : 16u) * row_bytes), kBufferFlags);
@@ -687,6 +690,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     const uint32_t out_tile_bytes = (uint32_t)Q.nb_out * 1024u;
     auto flush = [&]() {
         if (st_tile < 0) return;
+#ifdef HIGSFA_DIAG
+        if (P.whatif & 2) { st_tile = -1; return; }      // timing experiment: no stores
+#endif
         const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(Q.out + (size_t)st_tile * Q.nb_out * 64), 0, (int)out_tile_bytes, kBufferFlags);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, st_y0), r, (uint32_t)lane * 16u, (uint32_t)n1 * 1024u, 0);
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(st_y1), r, (uint32_t)lane * 16u, pk_off, 0);
