@@ -309,13 +309,13 @@ def main():
             k_name, k_ms, k_fl, k_by = kernels[k_pos]
             # HBM bytes of this launch: NOT measured in this run (PMC counters need their own rocprofv3 passes) but read
             # from the committed counter profile of the same configuration: entry of the same launch position whose
-            # rocprofv3 duration agrees with the live one within 20 % — otherwise the profile is stale and traffic is null
+            # rocprofv3 duration agrees with the live one within 15 % — otherwise the profile is stale and traffic is null
             traffic, traffic_source = None, None
             try:
-                if rows == ROWS_PER_GPU and in_dt == np.float32 and world == 1:
+                if rows == ROWS_PER_GPU and in_dt == np.float32 and world == 1 and args.node_kind == "pca_exp_sfa" and not args.generic:
                     tj = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_PROFILE)))
                     for key, val in tj.items():
-                        if key.startswith("%d|" % k_pos) and abs(val["avg_us"] - k_ms * 1e3) <= 0.2 * k_ms * 1e3:
+                        if key.startswith("%d|" % k_pos) and abs(val["avg_us"] - k_ms * 1e3) <= 0.15 * k_ms * 1e3:
                             traffic = val["hbm_read_bytes"] + val["hbm_write_bytes"]
                             traffic_source = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE of "
                                               "kernel %r, committed profile of this configuration, not measured in this run"
