@@ -47,6 +47,7 @@ struct FusedOptions {
     // match the per-layer kernels' throughput), so the default stops at 8 tiles.
     int chain_max_tiles = 8;
     bool no_pack = false;         // HIGSFA_NO_PACK: remainder tiles as whole blocks
+    uint32_t wq_start = 0;        // HIGSFA_WQ_START: initial value of the tile-queue counters (tests: wrap-around)
     bool no_direct = false;       // HIGSFA_NO_DIRECT: front kernel always stages the input rows through LDS (k_stage01p)
     bool no_fspec = false;        // HIGSFA_NO_FSPEC: front kernel without the compile-time (identity, abs-power) expansion
     int splitm_max_nodes = 4;     // experiments: HIGSFA_SPLITM_MAX
@@ -64,6 +65,7 @@ struct FusedOptions {
         o.no_pack = getenv("HIGSFA_NO_PACK") != nullptr;
         o.no_fspec = getenv("HIGSFA_NO_FSPEC") != nullptr;
         o.no_direct = getenv("HIGSFA_NO_DIRECT") != nullptr;
+        if (const char* e = getenv("HIGSFA_WQ_START")) o.wq_start = (uint32_t)strtoul(e, nullptr, 0);
         if (const char* e = getenv("HIGSFA_SPLITM_MAX")) o.splitm_max_nodes = atoi(e);
         if (const char* e = getenv("HIGSFA_SHAPES")) o.shape_variant = atoi(e);
         return o;
@@ -1596,8 +1598,10 @@ private:
         const size_t need = (size_t)n * 64;
         if (q.ctr.bytes < need) {
             q.ctr.alloc(std::max<size_t>(need, 64 * 1024));
-            HG_HIP(hipMemsetAsync(q.ctr.p, 0, q.ctr.bytes, st));
-            q.base = 0;
+            // counters and base start at the same value and only their difference matters; HIGSFA_WQ_START puts them just below
+            // 2^32 so that a test can cross the wrap-around that a long-running process reaches after ~10^7 calls
+            HG_HIP(hipMemsetD32Async((hipDeviceptr_t)q.ctr.p, (int)opt_.wq_start, q.ctr.bytes / 4, st));
+            q.base = opt_.wq_start;
         }
         return (uint32_t*)q.ctr.p;
     }

@@ -170,3 +170,24 @@ def test_front_kernel_variants_agree(native_lib, nets, monkeypatch):
     assert rel_err(direct.execute(x8[:64]), oracle.execute_flow(nodes, x8[:64])) <= TOL
     for f in (direct, staged, generic):
         f.close()
+
+
+def test_tile_queue_counters_wrap_around(native_lib, nets, monkeypatch):
+    """The front kernels hand tiles out through counters that are never reset: the host only tracks their base, modulo 2^32
+    (StageParams::work_ctr).  A process that serves frames for days crosses 2^32; here the counters start 300 below it, so
+    the second call of 256 tiles per queue wraps — and every call, before, across and after, must give the usual bits."""
+    nodes = nets("U11L-128")
+    x = synth.make_subimages(4096, 128, dtype=np.uint8)
+    usual = Flow(nodes, output_dtype=np.float32)
+    ref = usual.execute(x)
+    usual.close()
+    for variant in ({}, {"HIGSFA_NO_DIRECT": "1"}, {"HIGSFA_NO_DIRECT": "1", "HIGSFA_NO_FSPEC": "1"}):
+        monkeypatch.setenv("HIGSFA_WQ_START", "0xfffffed4")
+        for k, v in variant.items():
+            monkeypatch.setenv(k, v)
+        flow = Flow(nodes, output_dtype=np.float32)
+        for k in list(variant) + ["HIGSFA_WQ_START"]:
+            monkeypatch.delenv(k)
+        for n in (4096, 4096, 1000, 4096, 17, 4096):
+            assert np.array_equal(flow.execute(x[:n]), ref[:n]), (variant, n)
+        flow.close()
