@@ -359,6 +359,7 @@ void run_host_rows(hg_flow* f, Replica& rep, const void* x, int x_dtype, int64_t
     }
     if (n_chunks >= 2) unpack(n_chunks - 2);
     unpack(n_chunks - 1);
+    rep.exec->check_errors();      // everything has completed: a poll that ran out in one of the kernels fails THIS call
 }
 
 }  // namespace

@@ -96,6 +96,7 @@ public:
     // Enqueue on `stream`.  When ev != nullptr it holds n_stages()+1 events to record around stages.
     virtual void run(const void* x, int x_dtype, int64_t n, int64_t ldx, void* y, int y_dtype,
                      int64_t y_cols, int64_t ldy, hipStream_t stream, hipEvent_t* ev) = 0;
+    virtual void check_errors() {}                // after a synchronisation: did a kernel of an earlier run report a failure?
     virtual void release() = 0;                   // free device memory
 };
 

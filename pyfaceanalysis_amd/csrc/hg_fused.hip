@@ -48,6 +48,7 @@ struct FusedOptions {
     int chain_max_tiles = 8;
     bool no_pack = false;         // HIGSFA_NO_PACK: remainder tiles as whole blocks
     uint32_t wq_start = 0;        // HIGSFA_WQ_START: initial value of the tile-queue counters (tests: wrap-around)
+    bool no_wgq = false;          // HIGSFA_NO_WGQ: k_stage01d with one tile queue per layer-1 node instead of one per chunk (2-3 % faster, +29 % HBM bytes)
     bool no_direct = false;       // HIGSFA_NO_DIRECT: front kernel always stages the input rows through LDS (k_stage01p)
     bool no_fspec = false;        // HIGSFA_NO_FSPEC: front kernel without the compile-time (identity, abs-power) expansion
     int splitm_max_nodes = 4;     // experiments: HIGSFA_SPLITM_MAX
@@ -65,6 +66,7 @@ struct FusedOptions {
         o.no_pack = getenv("HIGSFA_NO_PACK") != nullptr;
         o.no_fspec = getenv("HIGSFA_NO_FSPEC") != nullptr;
         o.no_direct = getenv("HIGSFA_NO_DIRECT") != nullptr;
+        o.no_wgq = getenv("HIGSFA_NO_WGQ") != nullptr;
         if (const char* e = getenv("HIGSFA_WQ_START")) o.wq_start = (uint32_t)strtoul(e, nullptr, 0);
         if (const char* e = getenv("HIGSFA_SPLITM_MAX")) o.splitm_max_nodes = atoi(e);
         if (const char* e = getenv("HIGSFA_SHAPES")) o.shape_variant = atoi(e);
@@ -1181,6 +1183,7 @@ public:
 
     void run(const void* x, int x_dtype, int64_t n, int64_t ldx, void* y, int y_dtype, int64_t y_cols, int64_t ldy,
              hipStream_t st, hipEvent_t* ev) override {
+        check_device_error();      // of an earlier call: the word is host memory the kernels write through
         if (n > cap_rows_) reserve(n);
         // (Cutting a batch into row ranges on separate streams, plain or staggered, was measured and dropped: 0.69-0.84 ms
         // against 0.65 at N = 4096 — DESIGN.md §6.1.)
@@ -1336,11 +1339,12 @@ public:
                     // layers 0 and 1 in one persistent kernel; layer 1 writes where its own launch would
                     StageParams Q = base_params(stages_[1], nullptr, cur);
                     // every wave on its own (k_stage01d) where the input layout allows it, else the LDS-staged kernel
-                    const bool direct = fspec && s.direct_ok && stages_[1].pack_out && (int64_t)16 * ldx + 2048 < 0x7fffffffll && !opt_.no_direct;
-                    StageFn2 fn = direct ? pick_stage01d(x_dtype, false) : pick_stage01p(x_dtype, false, rem4, fspec);
+                    const bool direct = fspec && s.direct_ok && stages_[1].pack_out && (int64_t)16 * ldx + 2048 < 0x7fffffffll && s.max_chunk_nodes <= 8 && !opt_.no_direct;   // (k_stage01d: at most four waves)
+                    const bool wgq = !opt_.no_wgq;       // k_stage01d: one tile queue per chunk, shared by the waves of a workgroup
+                    StageFn2 fn = direct ? pick_stage01d(x_dtype, false, wgq) : pick_stage01p(x_dtype, false, rem4, fspec);
                     const int thr01 = 64 * std::max(1, (s.max_chunk_nodes + 1) / 2);   // one wave per pair of layer-0 nodes
                     // LDS: the tile buffers of FT batch tiles (k_stage01p only) + 10 vectors of 16 floats (means, biases) per wave
-                    const size_t lds2 = direct ? (size_t)(thr01 / 64) * 160 * 4
+                    const size_t lds2 = direct ? (size_t)4 * 160 * 4 + 8 * 8 + 4 * 4
                                                : (size_t)(kDoubleBuffer01 ? 2 : 1) * FT * 16 * s.lds_stride * 4 + (size_t)(thr01 / 64) * 160 * 4 + 16;   // + tile-group queue slots
                     const int groups2 = (n_tiles + FT - 1) / FT;
                     int occ = 1;
@@ -1361,16 +1365,17 @@ public:
                     if (opt_.debug) fprintf(stderr, "[front] occ %d threads %d lds %zu chunks %d tile_parts %d\n", occ, thr01, lds2, P.n_chunks, P.tile_parts);
 #ifdef HIGSFA_DIAG
                     if (opt_.stamp_stage == 0 && x_dtype == HG_F32) {
-                        fn = direct ? pick_stage01d(HG_F32, true) : pick_stage01p(HG_F32, true, rem4, fspec);
+                        fn = direct ? pick_stage01d(HG_F32, true, wgq) : pick_stage01p(HG_F32, true, rem4, fspec);
                         stamp_blocks_ = P.n_chunks * P.tile_parts;
                         stamp_buf_.alloc((size_t)stamp_blocks_ * 8 * 12 * 8);
                         HG_HIP(hipMemsetAsync(stamp_buf_.p, 0, stamp_buf_.bytes, st));
                         P.stamps = (unsigned long long*)stamp_buf_.p;
                     }
 #endif
-                    {   // k_stage01p: one queue of tile groups per chunk; k_stage01d: one queue of tiles per layer-1 node
-                        WorkQueue& wq = direct ? wq_direct_ : wq_front_;
-                        P.work_ctr = work_counters(wq, direct ? stages_[1].n_nodes : P.n_chunks, st);
+                    P.err = device_error_word();
+                    {   // k_stage01p: one queue of tile groups per chunk; k_stage01d: one queue of tiles per layer-1 node (or per chunk)
+                        WorkQueue& wq = direct ? (wgq ? wq_direct_wg_ : wq_direct_) : wq_front_;
+                        P.work_ctr = work_counters(wq, direct && !wgq ? stages_[1].n_nodes : P.n_chunks, st);
                         P.work_base = wq.base;
                         wq.base += (uint32_t)groups2;      // what this launch adds to every counter (StageParams::work_ctr)
                     }
@@ -1567,6 +1572,10 @@ public:
         chain_flags_.free();
         wq_front_.ctr.free();
         wq_direct_.ctr.free();
+        wq_direct_wg_.ctr.free();
+        if (err_host_) (void)hipHostFree(err_host_);
+        err_host_ = nullptr;
+        err_dev_ = nullptr;
         d_col_base_.free();
         for (auto& s : stages_) {
             s.d_afrag.free(); s.d_bias.free(); s.d_kb1tab.free(); s.d_chunks.free();
@@ -1604,6 +1613,23 @@ private:
             q.base = opt_.wq_start;
         }
         return (uint32_t*)q.ctr.p;
+    }
+
+    // Error word shared with the kernels that poll (k_chain, k_stage01d with the workgroup queue): pinned, device-mapped
+    // host memory, so the host can look at it without synchronising.  A poll only runs out on a bug; the run that hit it
+    // produced wrong features, and every later call on this flow fails loudly.
+    int32_t* device_error_word() {
+        if (!err_host_) {
+            HG_HIP(hipHostMalloc((void**)&err_host_, 64, hipHostMallocMapped));
+            *err_host_ = 0;
+            HG_HIP(hipHostGetDevicePointer((void**)&err_dev_, err_host_, 0));
+        }
+        return err_dev_;
+    }
+    void check_errors() override { check_device_error(); }
+    void check_device_error() {
+        if (err_host_ && *(volatile int32_t*)err_host_ != 0)
+            fail(HG_ERR_DEVICE, "fused: a bounded poll in a persistent kernel ran out (code %d); the features of that call are invalid", (int)*err_host_);
     }
 
     void set_lds_limit(StageFn fn, size_t bytes) {
@@ -2267,7 +2293,7 @@ private:
             HG_HIP(hipMemset(chain_flags_.p, 0, chain_flags_.bytes));      // generation 0 is never published
         }
         C.flags = (uint32_t*)chain_flags_.p + 16;
-        C.err = (int32_t*)chain_flags_.p;
+        C.err = device_error_word();
         C.gen = ++chain_gen_;
         if (chain_gen_ == 0xffffffffu) {      // wrap: start over with clean flags
             HG_HIP(hipMemsetAsync(chain_flags_.p, 0, chain_flags_.bytes, st));
@@ -2337,7 +2363,9 @@ private:
     std::vector<HostStage> stages_;
     std::vector<int32_t> col_base_;
     DevBuf d_col_base_, bufA_, bufB_, stamp_buf_;
-    WorkQueue wq_front_, wq_direct_;
+    WorkQueue wq_front_, wq_direct_, wq_direct_wg_;
+    int32_t* err_host_ = nullptr;
+    int32_t* err_dev_ = nullptr;
     int stamp_blocks_ = 0;
     std::map<const void*, size_t> lds_set_;
     std::map<std::tuple<const void*, int, size_t>, int> occ_;

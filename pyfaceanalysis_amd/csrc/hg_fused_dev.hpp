@@ -75,6 +75,7 @@ struct StageParams {
     // split the first workgroup of a CU finishes 25 % before the third and the kernel ends with a third of its waves.
     uint32_t* work_ctr;
     uint32_t work_base;
+    int32_t* err;       // host-visible error word: a bounded poll that ran out writes here (checked by the host at the next call)
     int32_t whatif;     // diagnostic build only (HIGSFA_WHATIF): bit 0 = k_stage reads every input block from the tile's first block (cache-hot),
                         // bit 1 = node_tail stores nothing — timing experiments, results are wrong
 };
@@ -320,7 +321,7 @@ StageFn pick_stage0(int mt1, int mt2, int T, int x_dtype);            // hg_fuse
 StageFn pick_stage0p(int x_dtype);
 StageFn2 pick_stage01p(int x_dtype, bool stamp, bool rem4, bool fspec);
 int stage01p_tiles(bool rem4, bool fspec);
-StageFn2 pick_stage01d(int x_dtype, bool stamp);       // every wave on its own, no LDS tile (hg_fused_front.hip)
+StageFn2 pick_stage01d(int x_dtype, bool stamp, bool wgq);       // every wave on its own, no LDS tile (hg_fused_front.hip)
 StageFn pick_igsfa(int ms, int mo, int T, int kb1);                   // hg_fused_igsfa.hip
 StageFn pick_igfold(int mo, int T);
 StageFn pick_prod(int mt1, int mt2, int T);                           // hg_fused_prod.hip

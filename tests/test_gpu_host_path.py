@@ -145,13 +145,16 @@ def test_persistent_top_of_hierarchy_launch(native_lib, nets, monkeypatch):
 
 
 def test_front_kernel_variants_agree(native_lib, nets, monkeypatch):
-    """Layers 0+1 of U11L-128 run on one of three kernels: every wave on its own with direct loads (k_stage01d, the default
-    for this layout), the LDS-staged form with the expansion known at compile time (HIGSFA_NO_DIRECT), and the generic
+    """Layers 0+1 of U11L-128 run on one of four kernels: every wave on its own with direct loads (k_stage01d, the default
+    for this layout; with one tile queue per chunk shared through an LDS ring or, HIGSFA_NO_WGQ, one per layer-1 node), the LDS-staged form with the expansion known at compile time (HIGSFA_NO_DIRECT), and the generic
     LDS-staged form (HIGSFA_NO_FSPEC).  All three hand tiles out dynamically (work counters that are never reset) and
     must give the same bits for every input type, for ragged batches, and call after call."""
     nodes = nets("U11L-128")
     x8 = synth.make_subimages(1000, 128, dtype=np.uint8)
     direct = Flow(nodes, output_dtype=np.float32)
+    monkeypatch.setenv("HIGSFA_NO_WGQ", "1")              # k_stage01d with one tile queue per layer-1 node
+    direct_wg = Flow(nodes, output_dtype=np.float32)
+    monkeypatch.delenv("HIGSFA_NO_WGQ")
     monkeypatch.setenv("HIGSFA_NO_DIRECT", "1")
     staged = Flow(nodes, output_dtype=np.float32)
     monkeypatch.setenv("HIGSFA_NO_FSPEC", "1")
@@ -163,12 +166,12 @@ def test_front_kernel_variants_agree(native_lib, nets, monkeypatch):
         for dt in (np.uint8, np.float32, np.float64):
             x = x8[:n].astype(dt)
             a = direct.execute(x)
-            assert np.array_equal(a, staged.execute(x)) and np.array_equal(a, generic.execute(x)), (n, dt)
+            assert np.array_equal(a, staged.execute(x)) and np.array_equal(a, generic.execute(x)) and np.array_equal(a, direct_wg.execute(x)), (n, dt)
             if n == 1000:
                 ref = a if ref is None else ref
                 assert np.array_equal(a, ref)
     assert rel_err(direct.execute(x8[:64]), oracle.execute_flow(nodes, x8[:64])) <= TOL
-    for f in (direct, staged, generic):
+    for f in (direct, direct_wg, staged, generic):
         f.close()
 
 
@@ -181,7 +184,7 @@ def test_tile_queue_counters_wrap_around(native_lib, nets, monkeypatch):
     usual = Flow(nodes, output_dtype=np.float32)
     ref = usual.execute(x)
     usual.close()
-    for variant in ({}, {"HIGSFA_NO_DIRECT": "1"}, {"HIGSFA_NO_DIRECT": "1", "HIGSFA_NO_FSPEC": "1"}):
+    for variant in ({}, {"HIGSFA_NO_WGQ": "1"}, {"HIGSFA_NO_DIRECT": "1"}, {"HIGSFA_NO_DIRECT": "1", "HIGSFA_NO_FSPEC": "1"}):
         monkeypatch.setenv("HIGSFA_WQ_START", "0xfffffed4")
         for k, v in variant.items():
             monkeypatch.setenv(k, v)
