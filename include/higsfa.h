@@ -42,7 +42,8 @@ enum hg_status {
     HG_ERR_ARG = -1,      /* null pointer, bad dtype, bad leading dimension, ...            */
     HG_ERR_FORMAT = -2,   /* malformed / truncated / unsupported blob                        */
     HG_ERR_DIM = -3,      /* input_dim / output_dim mismatch (MDP raises on these too)        */
-    HG_ERR_DEVICE = -4,   /* no HIP device, HIP call failed, flow not on a device             */
+    HG_ERR_DEVICE = -4,   /* no HIP device, HIP call failed, flow not on a device; also: a persistent kernel of an
+                           * earlier call on this flow reported a failed internal hand-off (its features are invalid) */
     HG_ERR_NOMEM = -5,
     HG_ERR_STATE = -6     /* call made in the wrong state (e.g. timings without profiling)    */
 };
