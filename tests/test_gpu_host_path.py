@@ -194,3 +194,31 @@ def test_tile_queue_counters_wrap_around(native_lib, nets, monkeypatch):
         for n in (4096, 4096, 1000, 4096, 17, 4096):
             assert np.array_equal(flow.execute(x[:n]), ref[:n]), (variant, n)
         flow.close()
+
+
+def test_device_resident_strided_rows(native_lib, nets):
+    """hg_flow_execute_device with sub-images that are rows of a wider device matrix (ldx > input_dim): the front kernel
+    addresses rows through the leading dimension (aligned ldx: fused layers-0+1 kernel with direct loads; ldx that breaks
+    the 16-byte alignment of the rows: the unfused first-layer kernels).  Same features as the dense matrix, within the
+    bound that holds across kernel choices."""
+    import torch
+    nodes = nets("U11L-128")
+    n = 200
+    x8 = synth.make_subimages(n, 128, dtype=np.uint8)
+    flow = Flow(nodes, output_dtype=np.float32)
+    dense = flow.execute(x8)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream(dev)
+    for np_dt, t_dt in ((np.float32, torch.float32), (np.uint8, torch.uint8), (np.float64, torch.float64)):
+        for pad, exact in ((64, True), (3, False)):
+            wide = torch.zeros((n, 16384 + pad), dtype=t_dt, device=dev)
+            wide[:, :16384] = torch.from_numpy(x8.astype(np_dt)).to(dev)
+            y = torch.empty((n, 60), dtype=torch.float32, device=dev)
+            flow.execute_device(wide.data_ptr(), np.dtype(np_dt), n, wide.shape[1], y.data_ptr(), np.float32, 60, 60, stream=stream.cuda_stream)
+            torch.cuda.synchronize()
+            got = y.cpu().numpy()
+            if exact:
+                assert np.array_equal(got, dense), (np_dt, pad)
+            else:
+                assert float(np.abs(got.astype(np.float64) - dense).max() / np.abs(dense).max()) <= 2e-6, (np_dt, pad)
+    flow.close()
