@@ -91,7 +91,7 @@ def cpu_baseline(nodes, n=256, reps=6):
     return out
 
 
-def frame_leg(flow, dev, reps=30, flow_factory=None):
+def frame_leg(flow, dev, reps=100, flow_factory=None):
     """BASELINE.json configs[2] as an extra figure beside the headline: one synthetic 1920x1080 frame, smallest_face 0.1,
     prescaled to 1000x562 (FaceDetectUpdated.py:551-556) -> 10 pyramid levels / 1738 first-stage windows of 128x128, all
     levels as ONE batch, through the synthetic 17-stage face cascade (pyfaceanalysis_amd/synth_cascade.py: the pipeline's
@@ -200,8 +200,10 @@ def frame_leg(flow, dev, reps=30, flow_factory=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # defaults: 0.55 s timed after 55 ms of warm-up.  A run of 20 steps after 3 (12 ms in all) ends before the chip has left its
+    # idle power state and reads 10 % low (0.611 against 0.552 / 0.547 ms per step at 200 / 1000 steps on one box)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--rows", type=int, default=ROWS_PER_GPU, help="sub-images per GPU per step")
     ap.add_argument("--input-dtype", default="float32", choices=["float32", "uint8", "float64"])
     ap.add_argument("--generic", action="store_true", help="force the generic plan (diagnostic)")
@@ -390,6 +392,8 @@ def main():
             roof["pipeline_tflops"] = flops_row * rows / (sum_ms * 1e-3) / 1e12
             roof["pipeline_frac"] = roof["pipeline_tflops"] / PEAK_MFMA_F32_TFLOPS
             roof["stages_ms"] = [round(ms, 4) for _, ms in stage_rows]
+            # the same against the untimed loop (the stage durations above carry ~3 us of event overhead each)
+            roof["pipeline_frac_timed_loop"] = flops_row * rows / (elapsed / args.steps) / 1e12 / PEAK_MFMA_F32_TFLOPS
         out = {
             "metric": "128x128 sub-images/sec through 11L HiGSFA net",
             "value": value, "unit": "sub-images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -52,7 +52,7 @@ dur = by_position([(short(r["Kernel_Name"]), r["Grid_Size_X"], (int(r["End_Times
                    for r in rows])
 fetch, write = counters("pmc_fetch_" + tag), counters("pmc_write_" + tag)
 sq, lds = counters("pmc_sq_" + tag), counters("pmc_lds_" + tag)
-lines = ["# rocprofv3 summary %s — `bench.py --steps 20 --warmup 3` (4096 x 128x128 fp32, U11L-128, 1 x MI355X)" % tag, "",
+lines = ["# rocprofv3 summary %s — `bench.py --steps 200 --warmup 30` (4096 x 128x128 fp32, U11L-128, 1 x MI355X; counter passes: 20 steps after 10)" % tag, "",
          "Durations: `rocprofv3 --kernel-trace --stats` (average over all dispatches of the run).  HBM bytes: separate",
          "`--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes, KiB -> bytes, FETCH_SIZE x2 (gfx950 reports half of wide",
          "coalesced reads, MI355X_MICROARCH.md §HBM).  MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles),",
