@@ -1468,7 +1468,7 @@ public:
                 static const int shapes0[][2] = {{8, 2}, {4, 2}, {4, 1}, {0, 0}};
                 static const int shapes1[][2] = {{8, 2}, {8, 1}, {4, 1}, {0, 0}};
                 static const int shapes2[][2] = {{8, 2}, {8, 1}, {4, 2}, {4, 1}};
-                const int (*shapes)[2] = opt_.shape_variant == 1 ? shapes1 : opt_.shape_variant == 2 ? shapes2 : shapes0;
+                const int (*shapes)[2] = opt_.shape_variant == 1 ? shapes1 : opt_.shape_variant == 3 ? shapes0 : shapes2;      // default: 8 x 1 before 4 x 2 (layer 7: 20.6 -> 19.0 us)
                 int nw = 4, T = 1;
                 for (int si2 = 0; si2 < 4; ++si2) {
                     const int* sh = shapes[si2];

@@ -139,6 +139,7 @@ __device__ __forceinline__ f32x4 apply_func_uniform(int func, float expo, f32x4 
 // k-steps r0 .. nk-1 of the block are multiplied (r0 > 0: a packed remainder block, whose leading k-steps belong to other nodes).
 template <int MT, int T, typename WP>
 __device__ __forceinline__ void gemm_block(WP wp, const f32x4 (&b)[T], f32x4 (&acc)[MT][T], int nk, int r0 = 0) {
+#ifndef HG_GEMM4_KOUTER      // (A/B switch: tools/ab_build.sh "-DHG_GEMM4_KOUTER")
     if constexpr (MT >= 4 && T >= 2) {
         // m-tile outer: one A fragment live (4 registers instead of 16).  In isolation this order is the slower one (a branch
         // and an exposed LDS read per pair of MFMAs: 88 % of the MFMA peak against 96 %, tools/ubench/mfma_loop.hip V5 / V4),
@@ -153,7 +154,10 @@ __device__ __forceinline__ void gemm_block(WP wp, const f32x4 (&b)[T], f32x4 (&a
                     for (int t = 0; t < T; ++t) acc[mt][t] = MFMA16(a[r], b[t][r], acc[mt][t]);
                 }
         }
-    } else {
+        return;
+    }
+#endif
+    {
         // k-step outer, m-tile inner: ONE branch per k-step and MT x T MFMAs behind it, all A fragments of the block read
         // from LDS up front (layer 2: 112 -> 105 us)
         f32x4 a[MT];
