@@ -10,7 +10,7 @@ blob, nodes = synth.cached_preset_blob("U11L-128")
 dev = torch.device("cuda", 0)
 n = 4096
 x = torch.from_numpy(synth.make_subimages(n, 128, dtype=np.float32)).to(dev)
-K = 40
+K = 1000
 for n_par in (1, 2, 3):
     flows = [Flow.from_blob(blob, device=0, output_dtype=np.float32) for _ in range(n_par)]
     ys = [torch.empty((n, 20), dtype=torch.float32, device=dev) for _ in range(n_par)]
@@ -23,7 +23,7 @@ for n_par in (1, 2, 3):
             i = s % n_par
             flows[i].execute_device(x.data_ptr(), np.dtype(np.float32), n, 16384, ys[i].data_ptr(), np.float32, 20, 20, stream=streams[i].cuda_stream)
         torch.cuda.synchronize()
-    run(6)
+    run(150)
     t0 = time.perf_counter()
     run(K)
     dt = time.perf_counter() - t0
