@@ -16,14 +16,16 @@ for n in (128, 340, 728, 1738):
     flow.reserve(max(n, 2048))
     def call(profile=False):
         flow.execute_device(x.data_ptr(), np.dtype(np.uint8), n, x.shape[1], y.data_ptr(), np.float32, 60, 60, stream=stream.cuda_stream, profile=profile)
-    for _ in range(20):
-        call()
-    torch.cuda.synchronize()
+    t_w = time.perf_counter()
+    while time.perf_counter() - t_w < 0.15:      # leave the idle power state (bench.py: settle)
+        for _ in range(20):
+            call()
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(200):
+    for _ in range(1000):
         call()
     torch.cuda.synchronize()
-    wall = (time.perf_counter() - t0) / 200 * 1e6
+    wall = (time.perf_counter() - t0) / 1000 * 1e6
     acc = None
     for _ in range(10):
         call(True); torch.cuda.synchronize()
