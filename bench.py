@@ -308,6 +308,26 @@ def main():
     y = sf.ys[(sf._n - 1) & 1]
     y_prof = torch.empty((rows, N_COLS), dtype=torch.float32, device=dev)
 
+    # --- per-kernel durations: HIP events recorded by the library around every stage launch, on
+    # the stream the kernels run on (separate passes, outside the timed region)
+    stage_rows = []
+    if rank == 0:
+        L = None
+        from pyfaceanalysis_amd import _capi
+        L = _capi.lib()
+        h = flow._handle()
+        prof_steps = max(5, min(11, args.steps))
+        samples, names = [], []
+        for _ in range(prof_steps):      # one sample per pass; the median drops a pass hit by a host hiccup
+            _capi.check(L.hg_flow_reset_profile(h.h))
+            flow.execute_device(x.data_ptr(), in_dt, rows, x.shape[1], y_prof.data_ptr(), np.float32, N_COLS, N_COLS,
+                                stream=stream.cuda_stream, profile=True)
+            torch.cuda.synchronize(dev)
+            st = flow.stage_times()
+            names = [nm for nm, _, _ in st]
+            samples.append([ms / max(cnt, 1) for _, ms, cnt in st])
+        stage_rows = list(zip(names, np.median(np.asarray(samples), axis=0).tolist()))
+
     # --- extra figure, NOT the headline: independent batches in flight.  `value` above is one batch after the other on one
     # stream (the contract's step, and what rocprofv3 sees).  A job that has many batches (frames, videos) can keep two or
     # three of them in flight on their own streams, each with its own flow handle and workspace: the ramp and the tail of
@@ -336,26 +356,6 @@ def main():
                                      "same_features_as_serial": bool(all(torch.equal(ys_f[i], y) for i in range(min(n_par, args.steps))))}
         for f in extra_flows:
             f.close()
-
-    # --- per-kernel durations: HIP events recorded by the library around every stage launch, on
-    # the stream the kernels run on (separate passes, outside the timed region)
-    stage_rows = []
-    if rank == 0:
-        L = None
-        from pyfaceanalysis_amd import _capi
-        L = _capi.lib()
-        h = flow._handle()
-        prof_steps = max(5, min(11, args.steps))
-        samples, names = [], []
-        for _ in range(prof_steps):      # one sample per pass; the median drops a pass hit by a host hiccup
-            _capi.check(L.hg_flow_reset_profile(h.h))
-            flow.execute_device(x.data_ptr(), in_dt, rows, x.shape[1], y_prof.data_ptr(), np.float32, N_COLS, N_COLS,
-                                stream=stream.cuda_stream, profile=True)
-            torch.cuda.synchronize(dev)
-            st = flow.stage_times()
-            names = [nm for nm, _, _ in st]
-            samples.append([ms / max(cnt, 1) for _, ms, cnt in st])
-        stage_rows = list(zip(names, np.median(np.asarray(samples), axis=0).tolist()))
 
     if rank == 0:
         # parity of the timed configuration on a slice of the batch (oracle = checker only)
