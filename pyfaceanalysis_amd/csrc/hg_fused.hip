@@ -45,13 +45,15 @@ struct FusedOptions {
     // batches of up to this many 16-row tiles run the top layers as one persistent launch (0: never).  Measured on U11L-128
     // (tools/small_batch2.py): 5-10 % of a call up to N = 128, a loss from N = 340 (one workgroup per node and slice cannot
     // match the per-layer kernels' throughput), so the default stops at 8 tiles.
-    int chain_max_tiles = 8;
+    int chain_max_tiles = 0;      // HIGSFA_CHAIN_MAX_TILES: the persistent chain (k_chain) is off by default — since every small layer runs on
+                                  // k_stage_splitm, five such launches (42 us at N <= 128) beat the chain's one (52 us)
     bool no_pack = false;         // HIGSFA_NO_PACK: remainder tiles as whole blocks
     uint32_t wq_start = 0;        // HIGSFA_WQ_START: initial value of the tile-queue counters (tests: wrap-around)
     bool no_wgq = false;          // HIGSFA_NO_WGQ: k_stage01d with one tile queue per layer-1 node instead of one per chunk (2-3 % faster, +29 % HBM bytes)
     bool no_direct = false;       // HIGSFA_NO_DIRECT: front kernel always stages the input rows through LDS (k_stage01p)
     bool no_fspec = false;        // HIGSFA_NO_FSPEC: front kernel without the compile-time (identity, abs-power) expansion
     int splitm_max_nodes = 4;     // experiments: HIGSFA_SPLITM_MAX
+    int splitm_max_wgs = 512;     // HIGSFA_SPLITM_WGS: largest k_stage_splitm grid for layers of more than splitm_max_nodes nodes
     int shape_variant = 0;        // experiments: HIGSFA_SHAPES
     static FusedOptions from_env() {
         FusedOptions o;
@@ -69,6 +71,7 @@ struct FusedOptions {
         o.no_wgq = getenv("HIGSFA_NO_WGQ") != nullptr;
         if (const char* e = getenv("HIGSFA_WQ_START")) o.wq_start = (uint32_t)strtoul(e, nullptr, 0);
         if (const char* e = getenv("HIGSFA_SPLITM_MAX")) o.splitm_max_nodes = atoi(e);
+        if (const char* e = getenv("HIGSFA_SPLITM_WGS")) o.splitm_max_wgs = atoi(e);
         if (const char* e = getenv("HIGSFA_SHAPES")) o.shape_variant = atoi(e);
         return o;
     }
@@ -431,7 +434,10 @@ __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
     // XCD-aware decode: blocks b, b+8, ... share an XCD (and its L2); give each XCD whole node
     // chunks so a chunk's weights are fetched into one L2 only.
     const int xcd = blockIdx.x & 7, kq = blockIdx.x >> 3;
-    const int chunk = xcd + 8 * (kq / P.tile_parts), part = kq % P.tile_parts;
+    // part-major within an XCD: the first workgroups dispatched — the oldest on their CUs, which the SIMD arbiter favours — are
+    // part 0 of EVERY chunk, so every node's tiles are served by fast and slow workgroups alike (chunk-major: +0.4 % per step)
+    const int cpx = (P.n_chunks + 7) >> 3;
+    const int chunk = xcd + 8 * (kq % cpx), part = kq / cpx;
     if (chunk >= P.n_chunks) return;
     const int n_begin = chunk * P.nodes_per_wg;
     const int n_end = min(n_begin + P.nodes_per_wg, P.n_nodes);
@@ -690,9 +696,10 @@ __global__ void __launch_bounds__(256) k_stage_splitm(StageParams P, int mt1n, i
             }
 #pragma unroll
             for (int k = 0; k < KB; ++k) {
+                const int nk = nks[k] & 255, r0 = nks[k] >> 8;      // (r0 > 0: a packed remainder block)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (r < nks[k]) {
+                    if (r >= r0 && r < nk) {
 #pragma unroll
                         for (int t = 0; t < T; ++t) z[t] = MFMA16(a1[k][r], bf[k][t][r], z[t]);
                     }
@@ -1439,9 +1446,15 @@ public:
                     hipLaunchKernelGGL(fn, (unsigned)blocks, T == 4 ? 512 : 256, lds_bytes, st, P);
                 }
             } else {
-                if (s.kind == 0 && s.n_nodes <= opt_.splitm_max_nodes && s.mt1 * s.nf <= 8 && (int64_t)s.n_nodes * n_tiles <= 8192) {
-                    // top of the hierarchy: split the m-tiles of a node over the waves of a small workgroup
-                    const int T = n_tiles >= 2 * 256 / std::max(1, s.n_nodes) ? 2 : 1;
+                // k_stage_splitm (one node and T tiles per small workgroup, weights straight from L2, no LDS copy): the top of the
+                // hierarchy at any batch size, and EVERY ordinary layer while its grid is small enough to be resident at once —
+                // a k_stage workgroup first copies 27-52 KiB of weights into LDS (5 us), which small batches never earn back
+                // (N = 16: 92 -> 70 us per call, N = 340: 137 -> 129, N = 1024: the same; grids of more than ~500 workgroups: k_stage wins)
+                const int T_sm = n_tiles >= 2 * 256 / std::max(1, s.n_nodes) ? 2 : 1;
+                const int64_t wgs_sm = (int64_t)((n_tiles + T_sm - 1) / T_sm) * s.n_nodes;
+                if (s.kind == 0 && !s.rem4 && !s.pack_out && s.mt1 * s.nf <= 8 &&
+                    (s.n_nodes <= opt_.splitm_max_nodes ? (int64_t)s.n_nodes * n_tiles <= 8192 : wgs_sm <= opt_.splitm_max_wgs)) {
+                    const int T = T_sm;
                     const int groups = (n_tiles + T - 1) / T;
                     const int nwv = std::max(s.mt1, s.has_exp ? s.mt2 : 1);
                     size_t lds_bytes = (size_t)std::max(1, s.nf) * s.mt1 * T * 1024;

@@ -117,17 +117,17 @@ def test_batch_size_dependence_is_bounded(native_lib, nets, monkeypatch):
 
 
 def test_persistent_top_of_hierarchy_launch(native_lib, nets, monkeypatch):
-    """Small batches (N <= 128) run the last layers of U11L-128 (16, 8, 4, 2, 1 nodes) as ONE persistent launch whose
+    """With HIGSFA_CHAIN_MAX_TILES set, small batches (N <= 128) run the last layers of U11L-128 (16, 8, 4, 2, 1 nodes) as ONE persistent launch whose
     workgroups hand tile groups from layer to layer through memory (hg_fused_chain.hip).  Same bits as the per-layer
     kernels; flags carry a generation number, so repeated calls and alternating batch sizes never see a stale hand-off."""
     nodes = nets("U11L-128")
     x = synth.make_subimages(300, 128, dtype=np.uint8)
+    monkeypatch.setenv("HIGSFA_CHAIN_MAX_TILES", "8")        # (off by default since the small layers run on k_stage_splitm)
     chain = Flow(nodes, output_dtype=np.float32)
     assert "one persistent launch" in chain.describe()
-    monkeypatch.setenv("HIGSFA_CHAIN_MAX_TILES", "0")
+    monkeypatch.delenv("HIGSFA_CHAIN_MAX_TILES")
     layers = Flow(nodes, output_dtype=np.float32)
     assert "persistent launch" not in layers.describe()
-    monkeypatch.delenv("HIGSFA_CHAIN_MAX_TILES")
     for n in (1, 16, 17, 128, 100, 1, 300, 33, 128):          # 300 > 128: both take the per-layer kernels
         a, b = chain.execute(x[:n]), layers.execute(x[:n])
         assert a.shape == (n, 60) and np.array_equal(a, b), n
