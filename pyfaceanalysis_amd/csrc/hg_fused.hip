@@ -650,7 +650,7 @@ __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
 // tiles; wave w computes m-tile w of GEMM 1 and later m-tile w of GEMM 2, so every weight block is
 // read by exactly one wave (straight from L2, all loads of a phase issued up front), and the
 // expanded z tiles are exchanged through 2*MT1*T KiB of LDS.
-template <int T>
+template <int T, bool REM = false>
 __global__ void __launch_bounds__(256) k_stage_splitm(StageParams P, int mt1n, int mt2n) {
     extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
     constexpr int KB = 8;   // K-blocks loaded per batch
@@ -675,7 +675,13 @@ __global__ void __launch_bounds__(256) k_stage_splitm(StageParams P, int mt1n, i
         for (int k = 0; k < KB; ++k)
             if (k < k2n) a2[k] = wnode[((size_t)P.kb1 * mt1n + (size_t)k * mt2n + w) * 64];
     }
-    f32x4 z[T];
+    // Remainder tiles (P.a4x4: the stage's last tile of both affines is stored in 4x4 form, hg_fused_dev.hpp): the wave that owns
+    // that tile multiplies with v_mfma_f32_4x4x1 into d4 and folds the four partial sums afterwards — the same products in the
+    // same order as the k_stage REM instantiations
+    const bool rem1 = REM && w == mt1n - 1, rem2 = REM && w == mt2n - 1;      // (REM instantiation <=> P.a4x4)
+    f32x4 z[T], d4[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) d4[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (w < mt1n) {
         const f32x4 bb = *(const f32x4*)(bnode + w * 16);
 #pragma unroll
@@ -694,16 +700,33 @@ __global__ void __launch_bounds__(256) k_stage_splitm(StageParams P, int mt1n, i
                     for (int t = 0; t < T; ++t) bf[k][t] = P.in[(size_t)(trow[t] + e.x) * 64 + lane];
                 }
             }
+            if (REM && rem1) {
 #pragma unroll
-            for (int k = 0; k < KB; ++k) {
-                const int nk = nks[k] & 255, r0 = nks[k] >> 8;      // (r0 > 0: a packed remainder block)
+                for (int k = 0; k < KB; ++k) {
+                    const int nk = nks[k] & 255, r0 = nks[k] >> 8;
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (r >= r0 && r < nk) {
+                    for (int r = 0; r < 4; ++r)
+                        if (r >= r0 && r < nk) {
 #pragma unroll
-                        for (int t = 0; t < T; ++t) z[t] = MFMA16(a1[k][r], bf[k][t][r], z[t]);
-                    }
+                            for (int t = 0; t < T; ++t) d4[t] = MFMA4(a1[k][r], bf[k][t][r], d4[t]);
+                        }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < KB; ++k) {
+                    const int nk = nks[k] & 255, r0 = nks[k] >> 8;      // (r0 > 0: a packed remainder block)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (r >= r0 && r < nk) {
+#pragma unroll
+                            for (int t = 0; t < T; ++t) z[t] = MFMA16(a1[k][r], bf[k][t][r], z[t]);
+                        }
+                }
             }
+        }
+        if (rem1) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) z[t] += rem4_rows(d4[t], g);
         }
         if (!P.has_exp) {
 #pragma unroll
@@ -722,6 +745,8 @@ __global__ void __launch_bounds__(256) k_stage_splitm(StageParams P, int mt1n, i
     }
     __syncthreads();
     if (w >= mt2n) return;
+#pragma unroll
+    for (int t = 0; t < T; ++t) d4[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 y[T];
     {
         const f32x4 bb = *(const f32x4*)(bnode + (mt1n + w) * 16);
@@ -736,12 +761,38 @@ __global__ void __launch_bounds__(256) k_stage_splitm(StageParams P, int mt1n, i
         f32x4 e[T];
 #pragma unroll
         for (int t = 0; t < T; ++t) e[t] = smem[((fi * mt1n + mt1) * T + t) * 64 + lane];
+        if (REM && rem2) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (r < nk) {
+            for (int r = 0; r < 4; ++r)
+                if (r < nk) {
 #pragma unroll
-                for (int t = 0; t < T; ++t) y[t] = MFMA16(a2[k][r], e[t][r], y[t]);
-            }
+                    for (int t = 0; t < T; ++t) d4[t] = MFMA4(a2[k][r], e[t][r], d4[t]);
+                }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (r < nk) {
+#pragma unroll
+                    for (int t = 0; t < T; ++t) y[t] = MFMA16(a2[k][r], e[t][r], y[t]);
+                }
+        }
+    }
+    if (rem2) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) y[t] += rem4_rows(d4[t], g);
+    }
+    if (REM && P.pack_base > 0) {      // packed remainder tiles (StageParams::pack_base): full tiles as blocks, the remainder rows into the shared block
+        if (rem2) {
+            const int slot = __builtin_amdgcn_readfirstlane(P.pack_slot[node]);
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+                if (tile[t] < P.n_tiles) ((float*)(P.out + ((size_t)tile[t] * P.nb_out + P.pack_base + (slot >> 2)) * 64 + lane))[slot & 3] = y[t][0];
+        } else {
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+                if (tile[t] < P.n_tiles) P.out[((size_t)tile[t] * P.nb_out + node * (mt2n - 1) + w) * 64 + lane] = y[t];
+        }
+        return;
     }
 #pragma unroll
     for (int t = 0; t < T; ++t)
@@ -1452,13 +1503,16 @@ public:
                 // (N = 16: 92 -> 70 us per call, N = 340: 137 -> 129, N = 1024: the same; grids of more than ~500 workgroups: k_stage wins)
                 const int T_sm = n_tiles >= 2 * 256 / std::max(1, s.n_nodes) ? 2 : 1;
                 const int64_t wgs_sm = (int64_t)((n_tiles + T_sm - 1) / T_sm) * s.n_nodes;
-                if (s.kind == 0 && !s.rem4 && !s.pack_out && s.mt1 * s.nf <= 8 &&
+                if (s.kind == 0 && (!s.rem4 || s.mt1 == s.mt2) && (s.rem4 || !s.pack_out) && s.mt1 * s.nf <= 8 &&
                     (s.n_nodes <= opt_.splitm_max_nodes ? (int64_t)s.n_nodes * n_tiles <= 8192 : wgs_sm <= opt_.splitm_max_wgs)) {
                     const int T = T_sm;
                     const int groups = (n_tiles + T - 1) / T;
                     const int nwv = std::max(s.mt1, s.has_exp ? s.mt2 : 1);
                     size_t lds_bytes = (size_t)std::max(1, s.nf) * s.mt1 * T * 1024;
-                    if (T == 2)
+                    if (s.rem4) {
+                        if (T == 2) hipLaunchKernelGGL((k_stage_splitm<2, true>), (unsigned)(groups * s.n_nodes), nwv * 64, lds_bytes, st, P, s.mt1, s.mt2);
+                        else hipLaunchKernelGGL((k_stage_splitm<1, true>), (unsigned)(groups * s.n_nodes), nwv * 64, lds_bytes, st, P, s.mt1, s.mt2);
+                    } else if (T == 2)
                         hipLaunchKernelGGL(k_stage_splitm<2>, (unsigned)(groups * s.n_nodes), nwv * 64, lds_bytes, st, P, s.mt1, s.mt2);
                     else
                         hipLaunchKernelGGL(k_stage_splitm<1>, (unsigned)(groups * s.n_nodes), nwv * 64, lds_bytes, st, P, s.mt1, s.mt2);
