@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 ROWS_PER_GPU = 4096
 N_COLS = 20                      # first 20 slow features are what callers consume
 SETTLE_MS = 150.0                # untimed load before short runs (see main)
+SETTLE_STEPS_DISTRIBUTED = 300   # the same as a fixed step count when every step ends in a collective
 SIDE = 128
 PRESET = "U11L-128"
 PEAK_MFMA_F32_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
@@ -278,10 +279,16 @@ def main():
     settle_ms = 0.0
     if args.warmup < 100:
         t_s = time.perf_counter()
-        while (time.perf_counter() - t_s) * 1e3 < SETTLE_MS:
-            for _ in range(10):
+        if distributed:
+            # every step ends in a collective: all ranks must run the SAME number of settle steps (a wall-clock loop would not)
+            for _ in range(SETTLE_STEPS_DISTRIBUTED):
                 step()
             torch.cuda.synchronize(dev)
+        else:
+            while (time.perf_counter() - t_s) * 1e3 < SETTLE_MS:
+                for _ in range(10):
+                    step()
+                torch.cuda.synchronize(dev)
         settle_ms = (time.perf_counter() - t_s) * 1e3
     for _ in range(args.warmup):
         step()
