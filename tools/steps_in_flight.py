@@ -8,7 +8,7 @@ from pyfaceanalysis_amd.flow import Flow
 
 blob, nodes = synth.cached_preset_blob("U11L-128")
 dev = torch.device("cuda", 0)
-n = 4096
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 x = torch.from_numpy(synth.make_subimages(n, 128, dtype=np.float32)).to(dev)
 K = 1000
 for n_par in (1, 2, 3):
