@@ -1397,7 +1397,7 @@ public:
                     // layers 0 and 1 in one persistent kernel; layer 1 writes where its own launch would
                     StageParams Q = base_params(stages_[1], nullptr, cur);
                     // every wave on its own (k_stage01d) where the input layout allows it, else the LDS-staged kernel
-                    const bool direct = fspec && s.direct_ok && stages_[1].pack_out && (int64_t)16 * ldx + 2048 < 0x7fffffffll && s.max_chunk_nodes <= 8 && !opt_.no_direct;   // (k_stage01d: at most four waves)
+                    const bool direct = fspec && s.direct_ok && stages_[1].pack_out && (int64_t)16 * ldx * (int64_t)esz + 2048 < 0x7fffffffll && s.max_chunk_nodes <= 8 && !opt_.no_direct;   // (k_stage01d: 32-bit byte offsets inside a tile's rows; at most four waves)
                     const bool wgq = !opt_.no_wgq;       // k_stage01d: one tile queue per chunk, shared by the waves of a workgroup
                     StageFn2 fn = direct ? pick_stage01d(x_dtype, false, wgq) : pick_stage01p(x_dtype, false, rem4, fspec);
                     const int thr01 = 64 * std::max(1, (s.max_chunk_nodes + 1) / 2);   // one wave per pair of layer-0 nodes
