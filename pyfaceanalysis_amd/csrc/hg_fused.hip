@@ -425,7 +425,7 @@ bool build_stages(const TNode& root, std::vector<FStage>& stages, std::string& w
 #else
 #define HG_HOT(blk) (blk)
 #endif
-template <int MT1, int MT2, int T, bool STAMP = false, bool REM = false, int KBF = 0>
+template <int MT1, int MT2, int T, bool STAMP = false, bool REM = false, int KBF = 0, bool FS = false>
 __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
     extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
     const int tid = threadIdx.x, nthr = blockDim.x;
@@ -543,7 +543,7 @@ __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
                         }
                     }
                     if (STAMP) ts1 = stamp_now();
-                    node_tail<MT1, MT2, T, REM>(P, wA2, b1 + MT1 * 16, g0 + ln, z, tile, lane);
+                    node_tail<MT1, MT2, T, REM, FS>(P, wA2, b1 + MT1 * 16, g0 + ln, z, tile, lane);
                     if (STAMP) {
                         unsigned long long ts2 = stamp_now();
                         t_g1 += ts1 - ts0;
@@ -614,7 +614,7 @@ __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
                     for (int t = 0; t < T; ++t) z[MT1 - 1][t] += rem4_rows(d4[t], g);
                 }
                 if (STAMP) ts1 = stamp_now();
-                node_tail<MT1, MT2, T, REM>(P, wA2, b1 + MT1 * 16, g0 + ln, z, tile, lane);
+                node_tail<MT1, MT2, T, REM, FS>(P, wA2, b1 + MT1 * 16, g0 + ln, z, tile, lane);
                 if (STAMP) {
                     unsigned long long ts2 = stamp_now();
                     t_g1 += ts1 - ts0;
@@ -829,7 +829,11 @@ StageFn pick_stage_m2(int mt2, int T) {
         default: return pick_stage_t<MT1, 4>(T);
     }
 }
-StageFn pick_stage(int mt1, int mt2, int T, bool rem = false, int kbf = 0) {
+StageFn pick_stage(int mt1, int mt2, int T, bool rem = false, int kbf = 0, bool fs = false) {
+    if (fs) {       // expansion (identity, |x|^p) at compile time: the shapes of the preset networks' middle layers
+        if (kbf == 3 && T == 2 && rem && mt1 == 3 && mt2 == 3) return (StageFn)k_stage<3, 3, 2, false, true, 3, true>;
+        if (kbf == 0 && !rem && mt1 == 4 && mt2 == 4) return T == 2 ? (StageFn)k_stage<4, 4, 2, false, false, 0, true> : (StageFn)k_stage<4, 4, 1, false, false, 0, true>;
+    }
     if (kbf == 4 && T == 2) {     // whole-visit prefetch (small nodes of four K-blocks; plan time checks kb1 == 4)
         if (rem && mt1 == 3 && mt2 == 3) return (StageFn)k_stage<3, 3, 2, false, true, 4>;
         if (rem && mt1 == 2 && mt2 == 2) return (StageFn)k_stage<2, 2, 2, false, true, 4>;
@@ -1556,7 +1560,8 @@ public:
                 size_t lds_probe = (size_t)npg * s.node_blocks * 1024 + (size_t)npg * s.bias_floats * 4 + (size_t)npg * s.kb1 * 8;
                 const int kbf = (T == 2 && s.mt1 == s.mt2 && (s.mt1 == 2 || s.mt1 == 3) && !opt_.no_prefetch_all)
                                     ? (s.kb1 == 4 ? 4 : (s.kb1 == 3 && s.rem4 ? 3 : 0)) : 0;
-                const double capacity = 256.0 * resident_blocks(pick_stage(s.mt1, s.mt2, T, s.rem4, kbf), nw * 64, lds_probe);
+                const bool fs = s.has_exp && s.nf == 2 && s.funcs[0].kind == E_IDENTITY && s.funcs[1].kind == E_ABS_POW && !opt_.no_fspec;
+                const double capacity = 256.0 * resident_blocks(pick_stage(s.mt1, s.mt2, T, s.rem4, kbf, fs), nw * 64, lds_probe);
                 int tile_parts = 1;
                 double best = 1e300;
                 for (int pp = 1; pp <= tile_groups; ++pp) {
@@ -1575,7 +1580,7 @@ public:
                 const int64_t blocks = (int64_t)((P.n_chunks + 7) / 8) * 8 * tile_parts;
                 if (blocks > 0x7fffffffll) fail(HG_ERR_ARG, "batch too large");
                 size_t lds_bytes = (size_t)npg * s.node_blocks * 1024 + (size_t)npg * s.bias_floats * 4 + (size_t)npg * s.kb1 * 8;
-                StageFn fn = pick_stage(s.mt1, s.mt2, T, s.rem4, kbf);
+                StageFn fn = pick_stage(s.mt1, s.mt2, T, s.rem4, kbf, fs);
 #ifdef HIGSFA_DIAG
                 const bool stamp_kbf3 = s.mt1 == 3 && s.mt2 == 3 && T == 2 && s.rem4 && kbf == 3;
                 if (opt_.stamp_stage == (int)si && (stamp_kbf3 || (s.mt1 == s.mt2 && (s.mt1 == 4 || s.mt1 == 3) && T == 2 && !s.rem4 && kbf == 0))) {

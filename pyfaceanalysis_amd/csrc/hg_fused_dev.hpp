@@ -223,7 +223,8 @@ __device__ __forceinline__ void gemm_block_rem(WP wp, const f32x4 (&b)[T], f32x4
 // Second half of a node: expansion of the z accumulators in registers, second affine, store.
 // wA2 / b2 point at this node's A2 fragments (+lane) and bias-2 fragment; address space (LDS or
 // global) is resolved after inlining.
-template <int MT1, int MT2, int T, bool REM = false, typename WP, typename BP>
+// FS: the expansion is (identity, |x|^p) and known at compile time (as in the front kernel): no function loop, no kind branches.
+template <int MT1, int MT2, int T, bool REM = false, bool FS = false, typename WP, typename BP>
 __device__ __forceinline__ void node_tail(const StageParams& P, WP wA2, BP b2, int node, f32x4 (&z)[MT1][T],
                                           const int (&tile)[T], int lane) {
     const int g = lane >> 4;
@@ -254,6 +255,20 @@ __device__ __forceinline__ void node_tail(const StageParams& P, WP wA2, BP b2, i
     f32x4 d4[T];      // REM: 4x4-form accumulators of the last output tile
 #pragma unroll
     for (int t = 0; t < T; ++t) d4[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (FS) {
+#pragma unroll
+        for (int mt1 = 0; mt1 < MT1; ++mt1) {
+            const uint32_t nkp = P.nk2p[mt1];
+            const int nk0 = nkp & 15, nk1 = (nkp >> 4) & 15;
+            if constexpr (REM) gemm_block_rem<MT2, T>(wA2 + (mt1 * 2) * MT2 * 64, z[mt1], y, d4, nk0);
+            else gemm_block<MT2, T>(wA2 + (mt1 * 2) * MT2 * 64, z[mt1], y, nk0);
+            f32x4 e[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) e[t] = pow_abs4(z[mt1][t], ex1);
+            if constexpr (REM) gemm_block_rem<MT2, T>(wA2 + (mt1 * 2 + 1) * MT2 * 64, e, y, d4, nk1);
+            else gemm_block<MT2, T>(wA2 + (mt1 * 2 + 1) * MT2 * 64, e, y, nk1);
+        }
+    } else
 #pragma unroll
     for (int mt1 = 0; mt1 < MT1; ++mt1) {
         const uint32_t nkp = P.nk2p[mt1];
