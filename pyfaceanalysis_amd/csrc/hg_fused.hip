@@ -526,7 +526,7 @@ __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
                     for (int kbi = 0; kbi < KBF; ++kbi) {
                         const int nkr = __builtin_amdgcn_readfirstlane(kt[kbi].y), nk = nkr & 255, r0 = nkr >> 8;
                         if constexpr (REM) gemm_block_rem<MT1, T>(wA1 + kbi * MT1 * 64, bq[kbi], z, d4, nk, r0);
-                        else gemm_block<MT1, T>(wA1 + kbi * MT1 * 64, bq[kbi], z, nk, r0);
+                        else gemm_block<MT1, T, FS>(wA1 + kbi * MT1 * 64, bq[kbi], z, nk, r0);
                     }
                     if constexpr (REM) {
 #pragma unroll
@@ -604,7 +604,7 @@ __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
 #pragma unroll
                     for (int t = 0; t < T; ++t) bfn[t] = P.in[(size_t)((in_group ? trow[t] : trow_nx[t]) + sbn) * 64 + lane];
                     if constexpr (REM) gemm_block_rem<MT1, T>(wA1 + kbi * MT1 * 64, bf, z, d4, nk & 255, nk >> 8);
-                    else gemm_block<MT1, T>(wA1 + kbi * MT1 * 64, bf, z, nk & 255, nk >> 8);
+                    else gemm_block<MT1, T, FS>(wA1 + kbi * MT1 * 64, bf, z, nk & 255, nk >> 8);
 #pragma unroll
                     for (int t = 0; t < T; ++t) bf[t] = bfn[t];
                     nk = nkn;

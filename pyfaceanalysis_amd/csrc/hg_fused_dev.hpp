@@ -137,13 +137,14 @@ __device__ __forceinline__ f32x4 apply_func_uniform(int func, float expo, f32x4 
 // One K-block: acc[mt][t] += A[mt] (16 x 16, four k-steps) * B[t].  `wp` points at the block's first
 // A fragment (+lane); fragments of consecutive m-tiles are 64 f32x4 apart.
 // k-steps r0 .. nk-1 of the block are multiplied (r0 > 0: a packed remainder block, whose leading k-steps belong to other nodes).
-template <int MT, int T, typename WP>
+template <int MT, int T, bool KOUT = false, typename WP>
 __device__ __forceinline__ void gemm_block(WP wp, const f32x4 (&b)[T], f32x4 (&acc)[MT][T], int nk, int r0 = 0) {
 #ifndef HG_GEMM4_KOUTER      // (A/B switch: tools/ab_build.sh "-DHG_GEMM4_KOUTER")
-    if constexpr (MT >= 4 && T >= 2) {
+    if constexpr (MT >= 4 && T >= 2 && !KOUT) {
         // m-tile outer: one A fragment live (4 registers instead of 16).  In isolation this order is the slower one (a branch
         // and an exposed LDS read per pair of MFMAs: 88 % of the MFMA peak against 96 %, tools/ubench/mfma_loop.hip V5 / V4),
-        // but inside k_stage<4,4,2> — 116 VGPRs this way, 127 the other — it measures 3-6 % FASTER on layers 3-5.
+        // but inside the generic k_stage<4,4,2> — 116 VGPRs this way, 127 the other — it measures 3 % FASTER on layers 3-5.
+        // (KOUT: the compile-time-expansion instantiations have registers to spare — 106 / 117 — and gain 0.3 % from the other order.)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const f32x4 a = wp[mt * 64];
@@ -261,12 +262,12 @@ __device__ __forceinline__ void node_tail(const StageParams& P, WP wA2, BP b2, i
             const uint32_t nkp = P.nk2p[mt1];
             const int nk0 = nkp & 15, nk1 = (nkp >> 4) & 15;
             if constexpr (REM) gemm_block_rem<MT2, T>(wA2 + (mt1 * 2) * MT2 * 64, z[mt1], y, d4, nk0);
-            else gemm_block<MT2, T>(wA2 + (mt1 * 2) * MT2 * 64, z[mt1], y, nk0);
+            else gemm_block<MT2, T, true>(wA2 + (mt1 * 2) * MT2 * 64, z[mt1], y, nk0);
             f32x4 e[T];
 #pragma unroll
             for (int t = 0; t < T; ++t) e[t] = pow_abs4(z[mt1][t], ex1);
             if constexpr (REM) gemm_block_rem<MT2, T>(wA2 + (mt1 * 2 + 1) * MT2 * 64, e, y, d4, nk1);
-            else gemm_block<MT2, T>(wA2 + (mt1 * 2 + 1) * MT2 * 64, e, y, nk1);
+            else gemm_block<MT2, T, true>(wA2 + (mt1 * 2 + 1) * MT2 * 64, e, y, nk1);
         }
     } else
 #pragma unroll
