@@ -1347,7 +1347,8 @@ public:
                 }
                 // folded layers stream their input blocks (k_igfold); HIGSFA_IG_RESIDENT=1 keeps them on k_igsfa
                 const bool igfold = s.ig_folded && !opt_.ig_resident;
-                StageFn fn = igfold ? pick_igfold(s.mt2, T) : pick_igsfa(s.mt1, s.mt2, T, s.kb1);
+                const bool ig_fs = igfold && s.nf == 2 && s.funcs[0].kind == E_IDENTITY && s.funcs[1].kind == E_ABS_POW && !opt_.no_fspec;
+                StageFn fn = igfold ? pick_igfold(s.mt2, T, ig_fs) : pick_igsfa(s.mt1, s.mt2, T, s.kb1);
                 const int ig_occ = resident_blocks(fn, std::max(nwt, 4) * 64, ig_lds);
                 const int nw = std::max(nwt, 4);   // never fewer than 4 waves to copy a node's weights
                 P.nodes_per_wg = nwt;

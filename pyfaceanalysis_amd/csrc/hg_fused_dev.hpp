@@ -343,7 +343,7 @@ StageFn2 pick_stage01p(int x_dtype, bool stamp, bool rem4, bool fspec);
 int stage01p_tiles(bool rem4, bool fspec);
 StageFn2 pick_stage01d(int x_dtype, bool stamp, bool wgq);       // every wave on its own, no LDS tile (hg_fused_front.hip)
 StageFn pick_igsfa(int ms, int mo, int T, int kb1);                   // hg_fused_igsfa.hip
-StageFn pick_igfold(int mo, int T);
+StageFn pick_igfold(int mo, int T, bool fs = false);
 StageFn pick_prod(int mt1, int mt2, int T);                           // hg_fused_prod.hip
 void launch_igfold_split(const StageParams& P, int mo, int n_tiles, hipStream_t st);                                                          // hg_fused_igsfa.hip
 void launch_im2frag(const void* x, int x_dtype, int64_t ldx, int64_t n_rows, int n_tiles, int nb, const int32_t* gcol, f32x4* out,

@@ -184,7 +184,8 @@ __global__ void __launch_bounds__((KBM == 6 ? 768 : 512), (KBM <= 4 ? 4 : KBM <=
 // the next batch-tile group, already in flight), expanded under every function and multiplied into the
 // output tiles at once.  ~100 VGPRs instead of 160-185: four waves per SIMD like k_stage.  Same workgroup
 // structure and LDS image ([fi][kb][mo] fragments, biases, means, block table) as k_igsfa.
-template <int MO, int T>
+// FS: the expansion is (identity, |x|^p), known at compile time (as in k_stage / the front kernel): no function loop, no kind branches
+template <int MO, int T, bool FS = false>
 __global__ void __launch_bounds__(512, 4) k_igfold(StageParams P) {
     extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, nw = nthr >> 6, g = lane >> 4;
@@ -258,6 +259,13 @@ __global__ void __launch_bounds__(512, 4) k_igfold(StageParams P) {
             f32x4 x0[T];
 #pragma unroll
             for (int t = 0; t < T; ++t) x0[t] = bf[t] - m;
+            if constexpr (FS) {
+                gemm_block<MO, T, true>(w1 + ((size_t)kb * MO) * 64, x0, y, nk);
+                f32x4 e[T];
+#pragma unroll
+                for (int t = 0; t < T; ++t) e[t] = pow_abs4(x0[t], P.expo[1]);
+                gemm_block<MO, T, true>(w1 + ((size_t)(kb1 + kb) * MO) * 64, e, y, nk);
+            } else
             for (int fi = 0; fi < nf; ++fi) {
                 f32x4 e[T];
                 const int fk = (P.funcp >> (4 * fi)) & 15;
@@ -372,7 +380,10 @@ void launch_igfold_split(const StageParams& P, int mo, int n_tiles, hipStream_t 
         hipLaunchKernelGGL(k_igfold_split<1>, (unsigned)(groups * P.n_nodes), nwv * 64, lds, st, P, mo);
 }
 
-StageFn pick_igfold(int mo, int T) {
+StageFn pick_igfold(int mo, int T, bool fs) {
+    if (fs && mo == 4) return T == 2 ? (StageFn)k_igfold<4, 2, true> : (StageFn)k_igfold<4, 1, true>;
+    if (fs && mo == 3) return T == 2 ? (StageFn)k_igfold<3, 2, true> : (StageFn)k_igfold<3, 1, true>;
+    if (fs && mo == 2) return T == 2 ? (StageFn)k_igfold<2, 2, true> : (StageFn)k_igfold<2, 1, true>;
     switch (mo) {
         case 1: return T == 2 ? (StageFn)k_igfold<1, 2> : (StageFn)k_igfold<1, 1>;
         case 2: return T == 2 ? (StageFn)k_igfold<2, 2> : (StageFn)k_igfold<2, 1>;
