@@ -832,6 +832,7 @@ StageFn pick_stage_m2(int mt2, int T) {
 StageFn pick_stage(int mt1, int mt2, int T, bool rem = false, int kbf = 0, bool fs = false) {
     if (fs) {       // expansion (identity, |x|^p) at compile time: the shapes of the preset networks' middle layers
         if (kbf == 3 && T == 2 && rem && mt1 == 3 && mt2 == 3) return (StageFn)k_stage<3, 3, 2, false, true, 3, true>;
+        if (kbf == 4 && T == 2 && !rem && mt1 == 3 && mt2 == 3) return (StageFn)k_stage<3, 3, 2, false, false, 4, true>;
         if (kbf == 0 && !rem && mt1 == 4 && mt2 == 4) return T == 2 ? (StageFn)k_stage<4, 4, 2, false, false, 0, true> : (StageFn)k_stage<4, 4, 1, false, false, 0, true>;
     }
     if (kbf == 4 && T == 2) {     // whole-visit prefetch (small nodes of four K-blocks; plan time checks kb1 == 4)
@@ -1395,14 +1396,14 @@ public:
                     rem4 = stages_[1].rem4 || (stages_[1].p_max <= 20 && stages_[1].s_max <= 20 && stages_[1].nk2[1][0] <= 1 &&
                                                stages_[1].nk2[1][1] <= 1 && !opt_.no_rem4);
                     auto id_pow = [](const HostStage& hs) { return hs.nf == 2 && hs.funcs[0].kind == E_IDENTITY && hs.funcs[1].kind == E_ABS_POW; };
-                    fspec = rem4 && id_pow(s) && id_pow(stages_[1]) && !opt_.no_fspec;
+                    fspec = id_pow(s) && id_pow(stages_[1]) && !opt_.no_fspec;
                 }
                 const int FT = stage01p_tiles(rem4, fspec);      // batch tiles per pass of the fused front kernel
                 if (fuse01_ && P.vec4 && n_tiles >= FT) {
                     // layers 0 and 1 in one persistent kernel; layer 1 writes where its own launch would
                     StageParams Q = base_params(stages_[1], nullptr, cur);
                     // every wave on its own (k_stage01d) where the input layout allows it, else the LDS-staged kernel
-                    const bool direct = fspec && s.direct_ok && stages_[1].pack_out && (int64_t)16 * ldx * (int64_t)esz + 2048 < 0x7fffffffll && s.max_chunk_nodes <= 8 && !opt_.no_direct;   // (k_stage01d: 32-bit byte offsets inside a tile's rows; at most four waves)
+                    const bool direct = fspec && rem4 && s.direct_ok && stages_[1].pack_out && (int64_t)16 * ldx * (int64_t)esz + 2048 < 0x7fffffffll && s.max_chunk_nodes <= 8 && !opt_.no_direct;   // (k_stage01d: 32-bit byte offsets inside a tile's rows; at most four waves)
                     const bool wgq = !opt_.no_wgq;       // k_stage01d: one tile queue per chunk, shared by the waves of a workgroup
                     StageFn2 fn = direct ? pick_stage01d(x_dtype, false, wgq) : pick_stage01p(x_dtype, false, rem4, fspec);
                     const int thr01 = 64 * std::max(1, (s.max_chunk_nodes + 1) / 2);   // one wave per pair of layer-0 nodes

@@ -883,7 +883,7 @@ StageFn pick_stage0p(int x_dtype) {
 // Tiles per pass of the instantiation pick_stage01p returns (the host sizes LDS and the group count with it): the
 // compile-time-expansion form takes ONE tile per pass at four waves per SIMD (124 VGPRs; 146 us against 153 with two
 // tiles at three waves), the generic form two tiles at three waves (168 VGPRs).
-int stage01p_tiles(bool rem4, bool fspec) { return rem4 && fspec ? 1 : 2; }
+int stage01p_tiles(bool rem4, bool fspec) { return fspec ? 1 : 2; }
 
 StageFn2 pick_stage01p(int x_dtype, bool stamp, bool rem4, bool fspec) {
     if (rem4) {
@@ -899,6 +899,9 @@ StageFn2 pick_stage01p(int x_dtype, bool stamp, bool rem4, bool fspec) {
 #ifdef HIGSFA_DIAG
     if (stamp && x_dtype == HG_F32) return (StageFn2)k_stage01p<float, true>;
 #endif
+    if (fspec)      // layer 1 without remainder tiles (e.g. folded iGSFA nodes): still one tile per pass, expansion at compile time
+        return x_dtype == HG_U8 ? (StageFn2)k_stage01p<uint8_t, false, false, 1, 1>
+                                : x_dtype == HG_F32 ? (StageFn2)k_stage01p<float, false, false, 1, 1> : (StageFn2)k_stage01p<double, false, false, 1, 1>;
     return x_dtype == HG_U8 ? (StageFn2)k_stage01p<uint8_t> : x_dtype == HG_F32 ? (StageFn2)k_stage01p<float> : (StageFn2)k_stage01p<double>;
 }
 
