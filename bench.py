@@ -199,6 +199,44 @@ def frame_leg(flow, dev, reps=100, flow_factory=None):
     return res
 
 
+def spawn_ranks(n_gpus, argv):
+    """`python bench.py --gpus N` (N > 1) without a launcher: this process has not imported torch.cuda work or touched HIP
+    and never will — it builds the native pieces if stale, starts `torch.distributed.run` with one rank per GPU as a fresh
+    CHILD process (never an exec of a process that holds the GPU), relays rank 0's single JSON line and returns the
+    child's exit code."""
+    import subprocess
+    from pyfaceanalysis_amd import build as native_build
+    if native_build.is_stale():
+        native_build.build()
+    oracle_dir = os.path.join(ROOT, "oracle")
+    if native_build.oracle_is_stale(oracle_dir):
+        subprocess.check_call(["make", "-s", "-C", oracle_dir])
+    import torch                                   # device_count() alone does not initialise the GPU
+    have = torch.cuda.device_count()
+    if have < n_gpus:
+        print("bench.py: --gpus %d asked for, %d GPU(s) visible on this node" % (n_gpus, have), file=sys.stderr)
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n_gpus) // n_gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node", str(n_gpus), os.path.abspath(__file__)] + list(argv)
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in child.stdout:                        # stderr goes straight through; stdout is scanned for the result line
+        if ln.startswith('{"metric"'):
+            line = ln.rstrip("\n")
+        else:
+            sys.stderr.write(ln)
+    rc = child.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        print("bench.py: the ranks exited with 0 but rank 0 printed no result line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -215,6 +253,8 @@ def main():
     ap.add_argument("--node-kind", default="pca_exp_sfa", choices=["pca_exp_sfa", "igsfa"],
                     help="node type of the synthetic 11-layer net (default: the BASELINE.md workload)")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -233,8 +273,7 @@ def main():
     import torch
     import torch.distributed as dist
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     # launched by torch.distributed.run (RANK set): the process-group path runs even with one rank, so that
@@ -309,9 +348,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # the gathered matrix holds this rank's block where the sharding says (checked outside the timed region)
-        last = (sf._n - 1) & 1
-        if not torch.equal(sf.y_alls[last][rank * rows:(rank + 1) * rows], sf.ys[last]):
-            raise SystemExit("bench.py: all-gather result does not contain this rank's features")
+        for b_ in ((0, 1) if sf._n >= 2 else ((sf._n - 1) & 1,)):       # both buffers: the last two steps' gathers
+            if not torch.equal(sf.y_alls[b_][rank * rows:(rank + 1) * rows], sf.ys[b_]):
+                raise SystemExit("bench.py: all-gather result (buffer %d) does not contain this rank's features" % b_)
+        # every rank's block arrived: the blocks differ (rank-seeded inputs) and none is left at its initial zeros
+        blocks = sf.y_alls[(sf._n - 1) & 1].view(world, rows, N_COLS)
+        if not bool((blocks.abs().amax(dim=(1, 2)) > 0).all()) or (world > 1 and torch.equal(blocks[0], blocks[1])):
+            raise SystemExit("bench.py: all-gather result misses a rank's block")
     y = sf.ys[(sf._n - 1) & 1]
     y_prof = torch.empty((rows, N_COLS), dtype=torch.float32, device=dev)
 

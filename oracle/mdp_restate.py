@@ -69,6 +69,9 @@ def apply_expfunc(f, x):
         if d - k <= 0:
             return np.zeros((x.shape[0], 0))
         return x[:, :d - k] * x[:, k:]
+    if f.kind == "pair_band":       # the other reading of pair_prodsadj{k}_ex: offsets 0 .. k-1, squares first
+        cols = [x[:, :d - off] * x[:, off:] for off in range(f.k) if d - off > 0]
+        return np.concatenate(cols, axis=1) if cols else np.zeros((x.shape[0], 0))
     raise ValueError("oracle: unknown expansion kind %r" % (f.kind,))
 
 

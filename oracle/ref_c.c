@@ -31,7 +31,8 @@ void ref_affine_f64(const double* x, long n, long ldx, long d_in, const double* 
 }
 
 /* One cuicuilco.nonlinear_expansion function (row a6).  kind: 0 identity, 1 |x|^p,
- * 2 sign(x)|x|^p, 3 x_i x_j (i<=j, i-major), 4 x_i x_{i+k}.  d = columns actually used.
+ * 2 sign(x)|x|^p, 3 x_i x_j (i<=j, i-major), 4 x_i x_{i+k}, 5 x_i x_{i+off} for off = 0..k-1 (offset-major; the
+ * other reading of pair_prodsadj{k}_ex).  d = columns actually used.
  * Returns the number of output columns written starting at y[.., 0]. */
 long ref_expfunc_f64(const double* x, long n, long ldx, long d, int kind, double expo, long k, double* y, long ldy) {
     long m = 0;
@@ -41,6 +42,7 @@ long ref_expfunc_f64(const double* x, long n, long ldx, long d, int kind, double
         case 2: m = d; break;
         case 3: m = d * (d + 1) / 2; break;
         case 4: m = d - k > 0 ? d - k : 0; break;
+        case 5: for (long off = 0; off < k && off < d; ++off) m += d - off; break;
         default: return -1;
     }
     for (long r = 0; r < n; ++r) {
@@ -61,6 +63,10 @@ long ref_expfunc_f64(const double* x, long n, long ldx, long d, int kind, double
                     for (long j = i; j < d; ++j) yr[o++] = xr[i] * xr[j];
                 break;
             case 4: for (long i = 0; i + k < d; ++i) yr[o++] = xr[i] * xr[i + k]; break;
+            case 5:
+                for (long off = 0; off < k; ++off)
+                    for (long i = 0; i + off < d; ++i) yr[o++] = xr[i + off] * xr[i];
+                break;
         }
     }
     return m;

@@ -47,7 +47,7 @@ def _names(obj):
     return [c.__name__ for c in type(obj).__mro__]
 
 
-_KIND = {"identity": 0, "abs_pow": 1, "signed_pow": 2, "quadratic": 3, "pair_adj": 4}
+_KIND = {"identity": 0, "abs_pow": 1, "signed_pow": 2, "quadratic": 3, "pair_adj": 4, "pair_band": 5}
 
 
 def _affine(x, a, W, b):

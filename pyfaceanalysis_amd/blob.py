@@ -36,7 +36,7 @@ K_IGSFA, K_IDENTITY, K_HEAD, K_CUTOFF, K_FLOWNODE = 7, 8, 9, 10, 11
 
 AFF_GENERIC, AFF_PCA, AFF_WHITENING, AFF_SFA, AFF_GSFA, AFF_LINREG = 0, 1, 2, 3, 4, 5
 IG_HAS_LR, IG_LR_UNSCALED, IG_SCALE_MATRIX = 1, 2, 4
-_EXP_KIND = {"identity": 0, "abs_pow": 1, "signed_pow": 2, "quadratic": 3, "pair_adj": 4}
+_EXP_KIND = {"identity": 0, "abs_pow": 1, "signed_pow": 2, "quadratic": 3, "pair_adj": 4, "pair_band": 5}
 _EXP_NAME = {v: k for k, v in _EXP_KIND.items()}
 
 

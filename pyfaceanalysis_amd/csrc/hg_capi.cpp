@@ -7,6 +7,7 @@
 #include <thread>
 
 #include "hg_common.hpp"
+#include "hg_hostpool.hpp"
 
 namespace {
 
@@ -37,82 +38,7 @@ void set_last_error(const std::string& s) { g_last_error = s; }
 
 namespace {
 
-// ---- host worker pool: packs caller rows into pinned staging buffers while the GPU works ------------
-// One parallel region at a time (callers from several threads queue up); workers are created on first use.
-class HostPool {
-public:
-    static HostPool& get() {
-        static HostPool p;
-        return p;
-    }
-    int size() const { return (int)workers_.size() + 1; }
-    // fn(task) for task in [0, n_tasks); the calling thread takes part.
-    void parallel_for(int n_tasks, const std::function<void(int)>& fn) {
-        if (n_tasks <= 1 || workers_.empty()) {
-            for (int t = 0; t < n_tasks; ++t) fn(t);
-            return;
-        }
-        std::lock_guard<std::mutex> region(region_);
-        {
-            std::lock_guard<std::mutex> lk(m_);
-            fn_ = &fn;
-            n_tasks_ = n_tasks;
-            next_.store(0);
-            pending_ = n_tasks;
-            ++gen_;
-        }
-        cv_.notify_all();
-        work();
-        std::unique_lock<std::mutex> lk(m_);
-        done_.wait(lk, [&] { return pending_ == 0; });
-        fn_ = nullptr;
-    }
-
-private:
-    HostPool() {
-        int n = (int)std::thread::hardware_concurrency();
-        if (const char* e = getenv("HIGSFA_HOST_THREADS")) n = atoi(e);
-        n = std::max(1, std::min(n, 16));
-        for (int i = 1; i < n; ++i) workers_.emplace_back([this] { loop(); });
-    }
-    ~HostPool() {
-        {
-            std::lock_guard<std::mutex> lk(m_);
-            stop_ = true;
-        }
-        cv_.notify_all();
-        for (auto& w : workers_) w.join();
-    }
-    void work() {
-        for (;;) {
-            const int t = next_.fetch_add(1);
-            if (t >= n_tasks_) return;
-            (*fn_)(t);
-            std::lock_guard<std::mutex> lk(m_);
-            if (--pending_ == 0) done_.notify_all();
-        }
-    }
-    void loop() {
-        uint64_t seen = 0;
-        for (;;) {
-            {
-                std::unique_lock<std::mutex> lk(m_);
-                cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
-                if (stop_) return;
-                seen = gen_;
-            }
-            work();
-        }
-    }
-    std::vector<std::thread> workers_;
-    std::mutex m_, region_;
-    std::condition_variable cv_, done_;
-    const std::function<void(int)>* fn_ = nullptr;
-    std::atomic<int> next_{0};
-    int n_tasks_ = 0, pending_ = 0;
-    uint64_t gen_ = 0;
-    bool stop_ = false;
-};
+using hg::HostPool;      // hg_hostpool.hpp
 
 }  // namespace
 
@@ -270,8 +196,8 @@ void run_on_device(hg_flow* f, const void* x, int x_dtype, int64_t n, int64_t ld
 // kernels run on the compute stream, and the features come back through a pinned slot as well.
 //   slot reuse: hx[b] after ev_h2d[b] (its H2D done); dx[b] / dy[b] / hy[b] after ev_out[b] (kernels + D2H of the
 //   chunk that used the slot done).
-void run_host_rows(hg_flow* f, Replica& rep, const void* x, int x_dtype, int64_t n, int64_t ldx, void* y, int y_dtype, int64_t y_cols,
-                   int64_t ldy, bool use_pool) {
+void run_host_rows_impl(hg_flow* f, Replica& rep, const void* x, int x_dtype, int64_t n, int64_t ldx, void* y, int y_dtype, int64_t y_cols,
+                        int64_t ldy, bool use_pool) {
     const size_t xs = hg::dtype_size(x_dtype), ys = hg::dtype_size(y_dtype);
     const int64_t in_dim = f->root->in_dim;
     // ~32 MiB of caller bytes per chunk (>= 256 rows): small enough to pipeline a 4096-row float64 batch in 16 chunks,
@@ -360,6 +286,20 @@ void run_host_rows(hg_flow* f, Replica& rep, const void* x, int x_dtype, int64_t
     if (n_chunks >= 2) unpack(n_chunks - 2);
     unpack(n_chunks - 1);
     rep.exec->check_errors();      // everything has completed: a poll that ran out in one of the kernels fails THIS call
+}
+
+// A call that fails half-way (a HIP error, a launch refused) must not leave copies and kernels in flight on the replica's
+// staging slots: the next call on the replica starts at chunk 0 / 1, which reuse the slots without waiting for an event, and
+// need_pinned may free and reallocate them.  Drain both streams before the error leaves.
+void run_host_rows(hg_flow* f, Replica& rep, const void* x, int x_dtype, int64_t n, int64_t ldx, void* y, int y_dtype, int64_t y_cols,
+                   int64_t ldy, bool use_pool) {
+    try {
+        run_host_rows_impl(f, rep, x, x_dtype, n, ldx, y, y_dtype, y_cols, ldy, use_pool);
+    } catch (...) {
+        if (rep.copy) (void)hipStreamSynchronize(rep.copy);
+        if (rep.compute) (void)hipStreamSynchronize(rep.compute);
+        throw;
+    }
 }
 
 }  // namespace
@@ -495,6 +435,13 @@ int hg_flow_execute_sharded(hg_flow* f, const void* x, int x_dtype, int64_t n, i
             if (devs[r] < 0 || devs[r] >= count) hg::fail(HG_ERR_DEVICE, "shard %d: device %d out of range (0..%d)", r, devs[r], count - 1);
         }
         if (n == 0) return;
+        // creating / destroying replicas moves the CALLING thread's current device: put it back when this call ends, so that
+        // the caller's later allocations and launches (torch) stay where they were
+        struct DeviceRestore {
+            int dev = -1;
+            DeviceRestore() { if (hipGetDevice(&dev) != hipSuccess) dev = -1; }
+            ~DeviceRestore() { if (dev >= 0) (void)hipSetDevice(dev); }
+        } restore_device;
         // replicas: one executor + streams + staging per listed device (a device may be listed more than once)
         if ((int)f->shards.size() > n_devices) {
             for (size_t r = n_devices; r < f->shards.size(); ++r) f->shards[r]->destroy();

@@ -404,8 +404,22 @@ int hg_cascade_detect_device(hg_cascade* c, const void* frame_dev, int frame_h, 
             HG_HIP(hipStreamSynchronize(st));          // idx / cnt0 are stack / heap temporaries
         }
         int cur = 0, cnt_slot = 0;
+        int sb = 0;                                    // which of subs[] holds the extracted sub-images, row-aligned with the candidates
         int64_t n_bound = n0, rows = 0;                // n_bound: host-side upper bound of the candidate count (exact after a Disc stage)
         const size_t row = (size_t)c->w * c->h;
+        // The reference compacts subimages_arr after EVERY stage (FaceDetectUpdated.py:753) and reuses it in a stage that follows a
+        // Disc stage and owns a network (:674-681).  Here the rows travel only while a later stage will read them before the next
+        // extraction replaces them: carry[k] = "stage k's survivors' sub-images are needed again".  (In the shipped pipeline that is
+        // after Disc1 / Disc3 / Disc5 / Disc7 only; a pipeline such as PosX(net), Disc(None), PosX(net) carries them through two stages.)
+        std::vector<char> carry((size_t)ns, 0);
+        {
+            bool need = false;                         // need at the entry of stage k + 1
+            for (int k = ns - 1; k >= 0; --k) {
+                carry[(size_t)k] = need;
+                const bool prev_disc = k > 0 && c->stages[k - 1].type == HG_STAGE_DISC;
+                if (c->stages[k].flow) need = prev_disc;          // reuses them (needs them at entry) or extracts afresh (does not)
+            }
+        }
         for (int k = 0; k < ns; ++k) {
             const hg_cascade_stage& S = c->stages[k];
             if (n_bound == 0) {
@@ -415,11 +429,11 @@ int hg_cascade_detect_device(hg_cascade* c, const void* frame_dev, int frame_h, 
             const bool skip_extract = (k > 0 && c->stages[k - 1].type == HG_STAGE_DISC) || !S.flow;      // FaceDetectUpdated.py:674-681
             if (!skip_extract) {
                 if (hg_patcher_extract_rotate_device(c->patcher, frame_dev, HG_U8, frame_h, frame_w, ld, (const double*)c->coords[cur].p,
-                                                     (const double*)c->neg.p, n_bound, c->w, c->h, c->subs[cur].p, HG_U8, (int64_t)row, st) != HG_OK)
+                                                     (const double*)c->neg.p, n_bound, c->w, c->h, c->subs[sb].p, HG_U8, (int64_t)row, st) != HG_OK)
                     hg::fail(HG_ERR_DEVICE, "%s", hg_last_error());
             }
             if (S.flow) {
-                if (hg_flow_execute_device(S.flow, c->subs[cur].p, HG_U8, n_bound, (int64_t)row, c->sl[cur].p, HG_F32, c->k, c->k, st) != HG_OK)
+                if (hg_flow_execute_device(S.flow, c->subs[sb].p, HG_U8, n_bound, (int64_t)row, c->sl[cur].p, HG_F32, c->k, c->k, st) != HG_OK)
                     hg::fail(HG_ERR_DEVICE, "%s", hg_last_error());
                 rows += n_bound;
             }
@@ -450,11 +464,11 @@ int hg_cascade_detect_device(hg_cascade* c, const void* frame_dev, int frame_h, 
             // the host needs the exact count only where it shrinks a lot and sizes expensive launches: after a Disc stage
             const bool want_count = S.type == HG_STAGE_DISC || k + 1 == ns;
             hipLaunchKernelGGL(k_cascade_stage, 1, 1024, 0, st, S.type, cc, A, want_count ? c->host_count : nullptr);
-            // the sub-images travel only to a stage that reuses them: one that follows a Disc stage and has a network (:674-677)
-            if (S.type == HG_STAGE_DISC && k + 1 < ns && c->stages[k + 1].flow) {
+            if (carry[(size_t)k]) {       // this stage's compaction applied to the sub-images as well (:753)
                 const int vec16 = row % 16 == 0 ? 1 : 0;
-                hipLaunchKernelGGL(k_gather_rows, (unsigned)std::min<int64_t>(n_bound, 16384), 256, 0, st, (const char*)c->subs[cur].p, (char*)c->subs[1 - cur].p,
+                hipLaunchKernelGGL(k_gather_rows, (unsigned)std::min<int64_t>(n_bound, 16384), 256, 0, st, (const char*)c->subs[sb].p, (char*)c->subs[1 - sb].p,
                                    (int64_t)row, (const int32_t*)c->map.p, (const int32_t*)A.count_out, vec16);
+                sb = 1 - sb;
             }
             HG_HIP(hipGetLastError());
             cur = 1 - cur;

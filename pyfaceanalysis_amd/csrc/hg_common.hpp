@@ -43,7 +43,9 @@ enum NodeKind : uint32_t {
     K_FLOW = 1, K_SWITCHBOARD = 2, K_LAYER = 3, K_CLONELAYER = 4, K_AFFINE = 5, K_EXPANSION = 6,
     K_IGSFA = 7, K_IDENTITY = 8, K_HEAD = 9, K_CUTOFF = 10, K_FLOWNODE = 11
 };
-enum ExpKind : uint32_t { E_IDENTITY = 0, E_ABS_POW = 1, E_SIGNED_POW = 2, E_QUADRATIC = 3, E_PAIR_ADJ = 4 };
+enum ExpKind : uint32_t { E_IDENTITY = 0, E_ABS_POW = 1, E_SIGNED_POW = 2, E_QUADRATIC = 3, E_PAIR_ADJ = 4, E_PAIR_BAND = 5 };
+// E_PAIR_ADJ / E_PAIR_BAND: the two readings of cuicuilco's pair_prodsadj{k}_ex (nodes.pair_prodsadj_ex): x_i x_{i+k} only, or the
+// reflexive band of offsets 0 .. k-1 stacked offset-major (squares first)
 
 struct ExpFunc {
     uint32_t kind, sel, k;
@@ -55,6 +57,11 @@ struct ExpFunc {
         int u = used(d);
         if (kind <= E_SIGNED_POW) return u;
         if (kind == E_QUADRATIC) return u * (u + 1) / 2;
+        if (kind == E_PAIR_BAND) {
+            int w = 0;
+            for (int off = 0; off < (int)k && off < u; ++off) w += u - off;
+            return w;
+        }
         return u - (int)k > 0 ? u - (int)k : 0;
     }
 };

@@ -2113,6 +2113,8 @@ private:
                 const int u = f.used(p);
                 if (f.kind == E_QUADRATIC) { for (int i = 0; i < u; ++i) for (int k = i; k < u; ++k) cols.push_back({fi, i, k}); }
                 else if (f.kind == E_PAIR_ADJ) for (int i = 0; i + (int)f.k < u; ++i) cols.push_back({fi, i, i + (int)f.k});
+                else if (f.kind == E_PAIR_BAND)
+                    for (int off = 0; off < (int)f.k; ++off) for (int i = 0; i + off < u; ++i) cols.push_back({fi, i, i + off});
             }
             return cols;
         };

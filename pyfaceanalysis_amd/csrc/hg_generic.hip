@@ -78,6 +78,13 @@ void add_expansion(Step& s, const std::vector<ExpFunc>& funcs, int d, int in_off
                     s.map.push_back(MapEntry{in_off + i, in_off + i + (int)f.k, M_PRODUCT, 0.f, m(i), m(i + f.k)});
                 }
                 break;
+            case E_PAIR_BAND:
+                for (int off = 0; off < (int)f.k; ++off)
+                    for (int i = 0; i + off < u; ++i) {
+                        s.map_cols.push_back(o++);
+                        s.map.push_back(MapEntry{in_off + i, in_off + i + off, M_PRODUCT, 0.f, m(i), m(i + off)});
+                    }
+                break;
         }
     }
 }

@@ -180,7 +180,7 @@ std::unique_ptr<TNode> read_node(Reader& r) {
                 f.sel = r.u32(p + 4);
                 f.k = r.u32(p + 8);
                 memcpy(&f.expo, p + 16, 8);
-                if (f.kind > E_PAIR_ADJ) fail(HG_ERR_FORMAT, "expansion: unknown function kind %u", f.kind);
+                if (f.kind > E_PAIR_BAND) fail(HG_ERR_FORMAT, "expansion: unknown function kind %u", f.kind);
                 // sel = number of leading columns the function reads (0 = all; more than there are = all, as numpy slicing
                 // clamps); k = pair distance
                 const uint64_t u = (f.sel && f.sel < n->in_dim) ? f.sel : n->in_dim;
@@ -189,7 +189,10 @@ std::unique_ptr<TNode> read_node(Reader& r) {
                 if (f.kind == E_PAIR_ADJ && (f.k == 0 || f.k >= u))
                     fail(HG_ERR_FORMAT, "expansion: pair distance %u outside 1..%llu", f.k, (unsigned long long)(u - 1));
                 // widths in 64 bits: u (u + 1) / 2 overflows int from u = 46341
-                const uint64_t w = f.kind <= E_SIGNED_POW ? u : f.kind == E_QUADRATIC ? u * (u + 1) / 2 : u - f.k;
+                if (f.kind == E_PAIR_BAND && (f.k == 0 || f.k > u))
+                    fail(HG_ERR_FORMAT, "expansion: band of %u offsets outside 1..%llu", f.k, (unsigned long long)u);
+                const uint64_t w = f.kind <= E_SIGNED_POW ? u : f.kind == E_QUADRATIC ? u * (u + 1) / 2
+                                   : f.kind == E_PAIR_BAND ? (uint64_t)f.k * u - (uint64_t)f.k * (f.k - 1) / 2 : u - f.k;
                 if (w == 0 || w > kMaxDim) fail(HG_ERR_FORMAT, "expansion: function %u is %llu columns wide", i, (unsigned long long)w);
                 if (w != (uint64_t)f.out_dim((int)n->in_dim)) fail(HG_ERR_FORMAT, "internal: expansion width");
                 total += w;

@@ -24,8 +24,7 @@ __all__ = [
     "Node", "IdentityNode", "HeadNode", "CutoffNode",
     "PCANode", "WhiteningNode", "SFANode", "GSFANode", "LinearRegressionNode",
     "ExpFunc", "GeneralExpansionNode",
-    "identity", "unsigned_08expo", "signed_08expo", "QT", "pair_prodsadj1_ex",
-    "pair_prodsadj2_ex", "unsigned_expo", "signed_expo", "sel_exp", "pair_prodsadj_ex",
+    "identity", "unsigned_08expo", "signed_08expo", "QT", "PAIR_READINGS", "unsigned_expo", "signed_expo", "sel_exp", "pair_prodsadj_ex",
     "iGSFANode", "IEVMLRecNode",
     "Switchboard", "PInvSwitchboard", "Rectangular2dSwitchboard",
     "Layer", "CloneLayer", "FlowNode",
@@ -147,9 +146,14 @@ class ExpFunc(object):
     signed_pow  sign(x) * abs(x) ** expo                     (d)
     quadratic   x_i * x_j for i <= j, i-major                (d (d + 1) / 2)
     pair_adj    x_i * x_{i+k} for i in range(d - k)          (d - k)
+    pair_band   hstack over off = 0 .. k-1 of x_i * x_{i+off} (squares first)   (sum of d - off)
+
+    ``pair_adj`` / ``pair_band`` are the two readings of cuicuilco's ``pair_prodsadj{k}_ex`` family that public
+    descriptions allow (is ``k`` ONE offset, or the number of offsets 0 .. k-1 of a reflexive band?); neither can be
+    checked in this repository, so the name alone never selects one — see ``pair_prodsadj_ex``.
     """
 
-    KINDS = ("identity", "abs_pow", "signed_pow", "quadratic", "pair_adj")
+    KINDS = ("identity", "abs_pow", "signed_pow", "quadratic", "pair_adj", "pair_band")
 
     def __init__(self, kind, expo=1.0, k=0, sel=0, name=None):
         if kind not in self.KINDS:
@@ -169,6 +173,8 @@ class ExpFunc(object):
             return d
         if self.kind == "quadratic":
             return d * (d + 1) // 2
+        if self.kind == "pair_band":
+            return sum(max(d - off, 0) for off in range(self.k))
         return max(d - self.k, 0)
 
     def __repr__(self):
@@ -179,8 +185,7 @@ identity = ExpFunc("identity", name="identity")
 unsigned_08expo = ExpFunc("abs_pow", expo=0.8, name="unsigned_08expo")
 signed_08expo = ExpFunc("signed_pow", expo=0.8, name="signed_08expo")
 QT = ExpFunc("quadratic", name="QT")
-pair_prodsadj1_ex = ExpFunc("pair_adj", k=1, name="pair_prodsadj1_ex")
-pair_prodsadj2_ex = ExpFunc("pair_adj", k=2, name="pair_prodsadj2_ex")
+PAIR_READINGS = ("offset", "band")
 
 
 def unsigned_expo(expo):
@@ -191,8 +196,19 @@ def signed_expo(expo):
     return ExpFunc("signed_pow", expo=expo, name="signed_expo(%g)" % expo)
 
 
-def pair_prodsadj_ex(k):
-    return ExpFunc("pair_adj", k=k, name="pair_prodsadj%d_ex" % k)
+def pair_prodsadj_ex(k, reading):
+    """cuicuilco.nonlinear_expansion ``pair_prodsadj{k}_ex`` under an EXPLICIT reading (no default, like
+    ``iGSFANode.lr_input``):
+
+    "offset"  products of columns exactly k apart:   x_i * x_{i+k}                      (d - k columns)
+    "band"    reflexive band of k offsets 0 .. k-1:  [x_i * x_i, x_i * x_{i+1}, ...]    (k d - k (k - 1) / 2 columns)
+    """
+    if reading not in PAIR_READINGS:
+        raise ValueError("pair_prodsadj%d_ex: state reading='offset' (x_i * x_{i+%d} only) or reading='band' (offsets 0..%d, "
+                         "squares included); the name does not decide it" % (k, k, k - 1))
+    if reading == "offset":
+        return ExpFunc("pair_adj", k=k, name="pair_prodsadj%d_ex[offset]" % k)
+    return ExpFunc("pair_band", k=k, name="pair_prodsadj%d_ex[band]" % k)
 
 
 def sel_exp(n, func):

@@ -17,6 +17,8 @@ class names (tests/test_pickle_import.py).
 """
 from __future__ import annotations
 
+import re
+
 import numpy as np
 
 from . import nodes as N
@@ -27,7 +29,7 @@ from .classifier import load_stub_pickle
 _FUNCS = {
     "identity": N.identity, "I": N.identity,
     "unsigned_08expo": N.unsigned_08expo, "signed_08expo": N.signed_08expo,
-    "QT": N.QT, "pair_prodsadj1_ex": N.pair_prodsadj1_ex, "pair_prodsadj2_ex": N.pair_prodsadj2_ex,
+    "QT": N.QT,
     "unsigned_2expo": N.unsigned_expo(2.0), "signed_2expo": N.signed_expo(2.0),
     "unsigned_06expo": N.unsigned_expo(0.6), "signed_06expo": N.signed_expo(0.6),
     "unsigned_09expo": N.unsigned_expo(0.9), "signed_09expo": N.signed_expo(0.9),
@@ -52,8 +54,20 @@ def _dims(obj):
     return int(_get(obj, "_input_dim", "input_dim")), int(_get(obj, "_output_dim", "output_dim"))
 
 
-def convert_func(f):
+_PAIR_NAME = re.compile(r"^pair_prodsadj(\d+)_ex$")
+
+
+def convert_func(f, pair_prodsadj_reading=None):
+    """One pickled expansion function (a global of cuicuilco.nonlinear_expansion, identified by NAME).
+    ``pair_prodsadj{k}_ex`` has two possible meanings (``nodes.pair_prodsadj_ex``); the caller must state which."""
     name = getattr(f, "__name__", None) or _cls(f)
+    m = _PAIR_NAME.match(name)
+    if m:
+        if pair_prodsadj_reading not in N.PAIR_READINGS:
+            raise ValueError("expansion function %r: state pair_prodsadj_reading='offset' (x_i * x_{i+k} only) or 'band' (offsets "
+                             "0 .. k-1, squares included) — the rule lives in cuicuilco @9bfd242, which is not available here, "
+                             "and the two give different (and differently wide) expansions" % name)
+        return N.pair_prodsadj_ex(int(m.group(1)), pair_prodsadj_reading)
     if name not in _FUNCS:
         raise TypeError("unsupported expansion function %r (module %r)" % (name, getattr(f, "__module__", "?")))
     return _FUNCS[name]
@@ -84,16 +98,18 @@ def _is_numeric_state(v):
     return isinstance(v, np.ndarray) and v.dtype.kind in "fiuc"
 
 
-def convert_node(obj, igsfa_lr_input=None, ignore_attrs=()):
+def convert_node(obj, igsfa_lr_input=None, ignore_attrs=(), pair_prodsadj_reading=None):
     """One pickled node (stub) -> a pyfaceanalysis_amd.nodes object.
 
     ``igsfa_lr_input``: "scaled" or "unscaled" — which slow features a pickled iGSFANode's ``lr_node`` reads
     (``nodes.iGSFANode``).  Required as soon as an iGSFANode has both a reconstruction and a non-trivial
     scaling; there is no default because the reference's source for it is not available.
-    ``ignore_attrs``: names of extra numeric attributes of iGSFANode stubs to accept unconsumed."""
+    ``ignore_attrs``: names of extra numeric attributes of iGSFANode stubs to accept unconsumed.
+    ``pair_prodsadj_reading``: "offset" or "band" — the meaning of ``pair_prodsadj{k}_ex`` (``nodes.pair_prodsadj_ex``);
+    required as soon as a pickled expansion names such a function, no default for the same reason."""
     if obj is None:
         return None
-    kw = dict(igsfa_lr_input=igsfa_lr_input, ignore_attrs=ignore_attrs)
+    kw = dict(igsfa_lr_input=igsfa_lr_input, ignore_attrs=ignore_attrs, pair_prodsadj_reading=pair_prodsadj_reading)
     name = _cls(obj)
     if name in ("PCANode", "WhiteningNode"):
         i, o = _dims(obj)
@@ -118,9 +134,11 @@ def convert_node(obj, igsfa_lr_input=None, ignore_attrs=()):
         return N.LinearRegressionNode(beta)
     if name == "GeneralExpansionNode":
         i, o = _dims(obj)
-        node = N.GeneralExpansionNode([convert_func(f) for f in _get(obj, "funcs")], i)
+        node = N.GeneralExpansionNode([convert_func(f, pair_prodsadj_reading) for f in _get(obj, "funcs")], i)
         if node.output_dim != o:
-            raise ValueError("GeneralExpansionNode: converted width %d != pickled output_dim %d" % (node.output_dim, o))
+            raise ValueError("GeneralExpansionNode: converted width %d != pickled output_dim %d%s" % (
+                node.output_dim, o, " (pair_prodsadj_reading=%r gives the wrong width: try the other reading)" % pair_prodsadj_reading
+                if any(f.kind in ("pair_adj", "pair_band") for f in node.funcs) else ""))
         return node
     if name in ("iGSFANode", "IEVMLRecNode"):
         consumed = {"x_mean", "exp_node", "sfa_node", "pca_node", "lr_node", "magn_n_sfa_x", "num_sfa_features_preserved",
@@ -192,12 +210,14 @@ def convert_flow_object(flow_obj, **kw):
     return out
 
 
-def load_flow_pickle(path, igsfa_lr_input=None, ignore_attrs=()):
-    return convert_flow_object(load_stub_pickle(path), igsfa_lr_input=igsfa_lr_input, ignore_attrs=ignore_attrs)
+def load_flow_pickle(path, igsfa_lr_input=None, ignore_attrs=(), pair_prodsadj_reading=None):
+    return convert_flow_object(load_stub_pickle(path), igsfa_lr_input=igsfa_lr_input, ignore_attrs=ignore_attrs,
+                               pair_prodsadj_reading=pair_prodsadj_reading)
 
 
-def pickle_to_blob(path, igsfa_lr_input=None, ignore_attrs=()):
-    return flow_to_blob(load_flow_pickle(path, igsfa_lr_input=igsfa_lr_input, ignore_attrs=ignore_attrs))
+def pickle_to_blob(path, igsfa_lr_input=None, ignore_attrs=(), pair_prodsadj_reading=None):
+    return flow_to_blob(load_flow_pickle(path, igsfa_lr_input=igsfa_lr_input, ignore_attrs=ignore_attrs,
+                                         pair_prodsadj_reading=pair_prodsadj_reading))
 
 
 if __name__ == "__main__":
@@ -207,6 +227,8 @@ if __name__ == "__main__":
     ap.add_argument("out")
     ap.add_argument("--igsfa-lr-input", choices=N.iGSFANode.LR_INPUTS, default=None,
                     help="which slow features the iGSFA linear reconstruction reads (no default: see nodes.iGSFANode)")
+    ap.add_argument("--pair-prodsadj-reading", choices=N.PAIR_READINGS, default=None,
+                    help="meaning of pair_prodsadj{k}_ex: x_i*x_{i+k} only, or offsets 0..k-1 (no default: see nodes.pair_prodsadj_ex)")
     a = ap.parse_args()
     with open(a.out, "wb") as fh:
-        fh.write(pickle_to_blob(a.pickle, igsfa_lr_input=a.igsfa_lr_input))
+        fh.write(pickle_to_blob(a.pickle, igsfa_lr_input=a.igsfa_lr_input, pair_prodsadj_reading=a.pair_prodsadj_reading))

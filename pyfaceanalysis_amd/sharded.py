@@ -41,12 +41,15 @@ class ShardedFlow(object):
     ``Flow.execute_device`` on this rank's GPU (``ShardedFlow.for_flow``); the CPU tests inject a callable.
 
     ``rows`` is the block size ceil(N / world) every rank allocates for; a rank may pass fewer rows
-    (the last block of a ragged batch), the rest of its block stays zero.
+    (the last block of a ragged batch): the rest of its block is zero in what the gather publishes
+    (the two feature buffers are reused, so ``step`` clears whatever an earlier, fuller step left
+    behind a short block).
     ``collective``: issue the all-gather (default: whenever a process group is initialised).
 
     On a GPU the gather of step i runs on a side stream under the kernels of step i+1 (two feature
     buffers, events in both directions); ``step`` returns the tensor the gather writes, valid once
-    ``wait()`` (or the returned tensor's stream dependencies) has been honoured.
+    ``wait()`` has returned or ``done_event(i)`` of that step has been waited for, and ONLY until step
+    i + 2 is enqueued, which writes the same buffer again: a consumer that needs it longer copies it.
     """
 
     def __init__(self, execute_local, n_cols, rows, device=None, collective=None):
@@ -67,6 +70,7 @@ class ShardedFlow(object):
         self.ys = [mk(self.rows), mk(self.rows)]
         self.y_alls = [mk(self.rows * self.world), mk(self.rows * self.world)] if self.collective else None
         self._n = 0
+        self._filled = [0, 0]          # rows of ys[b] that may hold features of an earlier step
         if self.cuda:
             self.stream = torch.cuda.current_stream(self.device)
             self.comm = torch.cuda.Stream(self.device) if self.collective else None
@@ -98,6 +102,13 @@ class ShardedFlow(object):
             raise ValueError("rank %d: local block has %d rows, more than the %d allocated" % (self.rank, m, self.rows))
         if self.cuda and self.collective:
             self.stream.wait_event(self.gathered[b])      # the gather that read ys[b] two steps ago is done
+        if m < self._filled[b]:         # a fuller step used this buffer before: its rows m.. must not be published again
+            if self.cuda:
+                with torch.cuda.stream(self.stream):
+                    self.ys[b][m:self._filled[b]].zero_()
+            else:
+                self.ys[b][m:self._filled[b]].zero_()
+        self._filled[b] = m
         if m:
             self.execute_local(x_local, self.ys[b][:m], self.stream.cuda_stream if self.cuda else 0)
         if not self.collective:
@@ -112,6 +123,16 @@ class ShardedFlow(object):
         else:
             gather_features(self.ys[b], self.y_alls[b])
         return self.y_alls[b]
+
+    def done_event(self, step_index=None):
+        """The event recorded after the gather of step ``step_index`` (default: the last one enqueued); only the
+        two most recent steps have one.  ``None`` on CPU or without a collective (then the result of a step is
+        ordered on ``self.stream`` itself)."""
+        last = self._n - 1
+        i = last if step_index is None else int(step_index)
+        if not (last - 1 <= i <= last) or i < 0:
+            raise ValueError("step %d: only the two most recent steps (%d, %d) still own a buffer" % (i, last - 1, last))
+        return self.gathered[i & 1] if (self.cuda and self.collective) else None
 
     def wait(self):
         """Block until everything enqueued so far (kernels and gathers) is complete."""

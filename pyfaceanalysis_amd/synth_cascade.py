@@ -38,26 +38,48 @@ def quantile_classifier(feats, d, labels, ridge=1e-3, device=0):
                               avg_labels=np.asarray(labels, dtype=np.float64), device=device)
 
 
-def build_face_cascade(flow, features, pipeline=None, keep_fraction=0.1, n_classes=10, device=0):
-    """Stages of the synthetic face cascade.  ``flow``: the Flow every network-owning stage runs (the reference uses four
-    trained flows of one architecture); ``features``: (m, >= 20) features of a sample of windows, used to calibrate the
-    classifiers so that the first Disc stage keeps about ``keep_fraction`` of the windows and the pose stages propose
-    small corrections inside their training ranges (Pipeline header: Dx 40, Dy 20, Dang 22.5, scale 0.694..0.981)."""
+# which of the pipeline's trained flows a network-owning stage runs (Pipelines/Pipeline_experimental.txt):
+# FaceCentering2 _1468510885 for Disc1/3/5/7, _1470325647 for Disc9, RTransXYPAngScale _1468325214 for iteration 0 and
+# _1468332771 for iterations 1-2 — four flows of one architecture
+FLOW_ROLE = {"Disc1": 0, "Disc3": 0, "Disc5": 0, "Disc7": 0, "Disc9": 1, "PosX0": 2, "PosX1": 3, "PosX2": 3}
+# classes of the reference's classifier files (SavedClassifiers/*.pckl): Disc (10, 9); pose regressors (50, 10) / (50, 20)
+N_CLASSES = {"Disc": 10, "PosX": 50, "PosY": 50, "PAng": 50, "Scale": 50}
+
+
+def build_face_cascade(flow, features, pipeline=None, keep_fraction=0.1, n_classes=None, device=0, stages=None):
+    """Stages of the synthetic face cascade.
+
+    ``flow``: ONE Flow that every network-owning stage runs, or a list of four (the reference's pipeline uses four trained
+    flows of one architecture: ``FLOW_ROLE``).  ``features``: (m, >= 20) features of a sample of windows — one array, or one
+    per flow — used to calibrate the classifiers so that the first Disc stage keeps about ``keep_fraction`` of the windows
+    and the pose stages propose small corrections inside their training ranges (Pipeline header: Dx 40, Dy 20, Dang 22.5,
+    scale 0.694..0.981).  ``n_classes``: classes of every classifier (default: the reference's files' — 10 for Disc, 50 for
+    the pose regressors).  ``stages``: another (name, owns a network, classifier width) list than ``FACE_STAGES``."""
     p = dict(grid.FACE_PIPELINE if pipeline is None else pipeline)
-    k = n_classes
-    n_face = max(1, int(round(k * keep_fraction)))
-    lab = {
-        "Disc": np.array([0.0] * n_face + [1.0] * (k - n_face)),
-        # small corrections: the synthetic networks carry no face semantics, so a window that moved far would get unrelated
-        # features at the next Disc stage and the cascade would die out after two iterations instead of exercising all 17
-        "PosX": np.linspace(-0.03 * p["net_Dx"], 0.03 * p["net_Dx"], k),
-        "PosY": np.linspace(-0.03 * p["net_Dy"], 0.03 * p["net_Dy"], k),
-        "PAng": np.linspace(-0.1 * p["net_Dang"], 0.1 * p["net_Dang"], k),
-        "Scale": np.linspace(0.815, 0.835, k),
-    }
-    stages = []
-    width = np.asarray(features).shape[1]
-    for name, own, d in FACE_STAGES:
-        d = min(d, width)                 # small test networks have fewer than 20 outputs
-        stages.append(Stage(name, flow if own else None, quantile_classifier(features, d, lab[name[:-1]], device=device)))
-    return stages
+    flows = list(flow) if isinstance(flow, (list, tuple)) else [flow] * 4
+    feats = list(features) if isinstance(features, (list, tuple)) else [features] * 4
+    if len(flows) != 4 or len(feats) != 4:
+        raise ValueError("build_face_cascade: one flow or four (FLOW_ROLE), with one feature sample each")
+
+    def labels(kind, k):
+        n_face = max(1, int(round(k * keep_fraction)))
+        return {
+            "Disc": np.array([0.0] * n_face + [1.0] * (k - n_face)),
+            # small corrections: the synthetic networks carry no face semantics, so a window that moved far would get unrelated
+            # features at the next Disc stage and the cascade would die out after two iterations instead of exercising all 17
+            "PosX": np.linspace(-0.03 * p["net_Dx"], 0.03 * p["net_Dx"], k),
+            "PosY": np.linspace(-0.03 * p["net_Dy"], 0.03 * p["net_Dy"], k),
+            "PAng": np.linspace(-0.1 * p["net_Dang"], 0.1 * p["net_Dang"], k),
+            "Scale": np.linspace(0.815, 0.835, k),
+        }[kind]
+    out = []
+    role = 0
+    for name, own, d in (FACE_STAGES if stages is None else stages):
+        if own:
+            role = FLOW_ROLE.get(name, 0)          # a stage without a network reads the features of the last flow that ran
+        f = np.asarray(feats[role])
+        d = min(d, f.shape[1])                     # small test networks have fewer than 20 outputs
+        k = N_CLASSES[name[:-1]] if n_classes is None else n_classes
+        k = max(2, min(k, len(f) // 4))            # tiny calibration samples: fewer classes than rows
+        out.append(Stage(name, flows[role] if own else None, quantile_classifier(f, d, labels(name[:-1], k), device=device)))
+    return out

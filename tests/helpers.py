@@ -71,7 +71,7 @@ def linear_u11l_96(seed=0):
 def product_net(seed=0):
     """Expansions with cross-column products (QT, pair products), HeadNode, CutoffNode: generic plan."""
     rng = np.random.default_rng(seed)
-    funcs = [N.identity, N.QT, N.pair_prodsadj1_ex, N.sel_exp(4, N.pair_prodsadj2_ex)]
+    funcs = [N.identity, N.QT, N.pair_prodsadj_ex(1, "offset"), N.sel_exp(4, N.pair_prodsadj_ex(2, "band"))]
     sb0 = N.Rectangular2dSwitchboard((8, 8), (4, 4), (4, 4), 1)
     l0 = []
     for _ in range(4):
@@ -91,7 +91,7 @@ def product_hier_net(seed=0, side=64):
     for li, (p, s_out) in enumerate(dims):
         field = (4, 4) if li == 0 else ((2, 1) if (li % 2 == 1 and w > 1) or h == 1 else (1, 2))
         sb = N.Rectangular2dSwitchboard((w, h), field, field, c)
-        funcs = [N.identity, N.sel_exp(6, N.QT), N.pair_prodsadj1_ex, N.unsigned_08expo]
+        funcs = [N.identity, N.sel_exp(6, N.QT), N.pair_prodsadj_ex(1, "offset"), N.unsigned_08expo]
         nodes = []
         for _ in range(sb.output_channels):
             ex = N.GeneralExpansionNode(funcs, p)
@@ -122,11 +122,14 @@ def fuzz_product_net(seed):
         n_nodes, d_in = sb.output_channels, sb.out_channel_dim
         p0 = int(rng.integers(3, min(d_in, 12) + 1))
         s0 = int(rng.integers(2, 30))
-        pool = [N.identity, N.QT, N.pair_prodsadj1_ex, N.pair_prodsadj2_ex, N.unsigned_08expo, N.signed_expo(float(rng.uniform(0.6, 1.2))),
-                N.sel_exp(int(rng.integers(2, p0)), N.QT), N.sel_exp(int(rng.integers(3, p0 + 1)), N.pair_prodsadj1_ex), N.pair_prodsadj_ex(2)]
+        # both readings of pair_prodsadj{k}_ex (nodes.pair_prodsadj_ex): x_i x_{i+k} only ("offset"), offsets 0 .. k-1 ("band")
+        pool = [N.identity, N.QT, N.pair_prodsadj_ex(1, "offset"), N.pair_prodsadj_ex(2, "offset"), N.unsigned_08expo,
+                N.signed_expo(float(rng.uniform(0.6, 1.2))), N.sel_exp(int(rng.integers(2, p0)), N.QT),
+                N.sel_exp(int(rng.integers(3, p0 + 1)), N.pair_prodsadj_ex(1, "offset")), N.pair_prodsadj_ex(2, "band"),
+                N.pair_prodsadj_ex(1, "band"), N.sel_exp(int(rng.integers(3, p0 + 1)), N.pair_prodsadj_ex(3, "band"))]
         nf = int(rng.integers(2, 6))
         funcs = [pool[int(i)] for i in rng.choice(len(pool), nf, replace=False)]
-        if not any(f.kind in ("quadratic", "pair_adj") for f in funcs):
+        if not any(f.kind in ("quadratic", "pair_adj", "pair_band") for f in funcs):
             funcs[-1] = N.QT
         uneven = rng.random() < 0.4
         clip = rng.random() < 0.4

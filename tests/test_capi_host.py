@@ -129,8 +129,10 @@ def test_malformed_expansion_records_are_rejected(native_lib):
         kind, sel, k, expo = fields.get("kind", kind), fields.get("sel", sel), fields.get("k", k), fields.get("expo", expo)
         return good[:off] + struct.pack("<IIIId", kind, sel, k, 0, expo) + good[off + 24:]
 
-    cases = [patched(N.pair_prodsadj1_ex, k=0xFFFFFFFF),        # x_i * x_{i-1}: reads below the block
-             patched(N.pair_prodsadj1_ex, k=0), patched(N.pair_prodsadj1_ex, k=8),
+    pp1, band2 = N.pair_prodsadj_ex(1, "offset"), N.pair_prodsadj_ex(2, "band")
+    cases = [patched(pp1, k=0xFFFFFFFF),        # x_i * x_{i-1}: reads below the block
+             patched(pp1, k=0), patched(pp1, k=8),
+             patched(band2, k=0), patched(band2, k=9), patched(band2, k=0xFFFFFFFF), patched(band2, kind=6),
              patched(N.sel_exp(3, N.QT), sel=5),                 # selection changed, output width no longer matches
              patched(N.unsigned_08expo, expo=float("nan")), patched(N.unsigned_08expo, expo=-0.5),
              patched(N.signed_08expo, expo=float("inf"))]
@@ -138,7 +140,7 @@ def test_malformed_expansion_records_are_rejected(native_lib):
         rc, h = _load(native_lib, b)
         assert rc in (_capi.HG_ERR_FORMAT, _capi.HG_ERR_DIM), native_lib.hg_last_error()
         assert b"expansion" in native_lib.hg_last_error()
-    good = [blob.flow_to_blob(x) for x in (net(N.pair_prodsadj1_ex), net(N.QT), net(N.sel_exp(3, N.QT)), net(N.unsigned_expo(1.3)))]
+    good = [blob.flow_to_blob(x) for x in (net(pp1), net(band2), net(N.pair_prodsadj_ex(8, "band")), net(N.QT), net(N.sel_exp(3, N.QT)), net(N.unsigned_expo(1.3)))]
     # a selection wider than the block reads all of it (numpy slicing clamps; cuicuilco's sel_exp): 9 of 8, 0xFFFFFFFE of 8
     good += [patched(N.QT, sel=9), patched(N.QT, sel=0xFFFFFFFE)]
     for b in good:

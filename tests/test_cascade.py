@@ -60,19 +60,37 @@ def test_stage_loop_on_cpu_callables():
     assert len(out["coords"]) == out["counts"][-1] == len(out["confidence"])
 
 
+# stage sequences the shipped pipeline does not contain but hg_cascade_create accepts: sub-images extracted at one stage and
+# reused after a Disc stage WITHOUT a network, or after two Disc stages in a row of which the first had no reason to pass
+# them on (the reference compacts subimages_arr at every stage, FaceDetectUpdated.py:753, and reuses it, :674-681)
+AWKWARD = {
+    "pipeline": None,
+    "disc_without_network_then_reuse": [("Disc1", True, 9), ("PosX0", True, 10), ("Disc3", False, 9), ("PosX1", True, 10), ("PosY1", False, 10),
+                                        ("Disc5", True, 9), ("Disc7", False, 9), ("Disc9", True, 9)],
+    "two_disc_then_reuse": [("Disc1", True, 9), ("Disc3", False, 9), ("Disc5", False, 9), ("PosX0", True, 10), ("PAng0", False, 10),
+                            ("Scale0", True, 10), ("Disc7", False, 9), ("PosY0", False, 10), ("Disc9", True, 9), ("PosX1", True, 10)],
+}
+
+
 @pytest.mark.gpu
-def test_device_cascade_matches_restated_loop(native_lib, nets):
+@pytest.mark.parametrize("sequence", sorted(AWKWARD))
+def test_device_cascade_matches_restated_loop(native_lib, nets, sequence):
     """DeviceCascade (extract -> execute -> regression -> update -> discard -> compaction, all on the GPU) against the
-    restated stage loop driven by PIL windows and the SAME device features/regression (so only the glue is compared):
-    identical survivor sets, counts, coordinates and angles; then the features themselves against the oracle."""
+    restated stage loop driven by PIL windows and the SAME device features (so only the glue is compared): identical
+    survivor sets, counts, coordinates and angles; the device regression of EVERY stage against the C restatement
+    (oracle/ref_c.c gauss_regression) on the same features; then the features themselves against the oracle.
+    Four distinct flow handles play the pipeline's four flows (synth_cascade.FLOW_ROLE)."""
     import torch
     from oracle import mdp_restate, pil_restate
     from pyfaceanalysis_amd import synth_cascade
     from pyfaceanalysis_amd.cascade import DeviceCascade, frame_windows
     from pyfaceanalysis_amd.flow import Flow
     from pyfaceanalysis_amd.patches import Patcher
+    from oracle import ref_c
     nodes = nets("T5L-16")
     flow = Flow(nodes, output_dtype=np.float32)
+    nodes4 = [nodes] + [nets("T5L-16", seed=777 + i) for i in range(3)]
+    flows = [flow] + [Flow(nd, output_dtype=np.float32) for nd in nodes4[1:]]
     rng = np.random.default_rng(21)
     frame = np.rint(rng.integers(0, 256, (90, 160)).astype(np.float64)).astype(np.uint8)
     pipe = dict(grid.FACE_PIPELINE)
@@ -81,7 +99,8 @@ def test_device_cascade_matches_restated_loop(native_lib, nets):
     pt = Patcher()
     subs0 = pt.extract(frame, boxes, (16, 16), dtype=np.uint8)
     feats = flow.execute(subs0)
-    stages = synth_cascade.build_face_cascade(flow, feats, pipe, keep_fraction=0.4)
+    stages = synth_cascade.build_face_cascade(flows, [f.execute(subs0) for f in flows], pipe, keep_fraction=0.4, stages=AWKWARD[sequence])
+    assert len({id(s.flow) for s in stages if s.flow is not None}) >= 3
     dc = DeviceCascade(stages, (16, 16), K, pipe)
     got = dc.detect(torch.from_numpy(frame).cuda(), smallest_face=0.3)
 
@@ -89,27 +108,38 @@ def test_device_cascade_matches_restated_loop(native_lib, nets):
         return pt.extract(frame, coords, (16, 16), dtype=np.uint8, delta_angs=dang) if len(coords) else np.zeros((0, 256), np.uint8)
 
     def execute(k, subs):
-        return flow.execute(subs)
+        return stages[k].flow.execute(subs)
+
+    checked = []
 
     def regress(k, sl):
-        return stages[k].classifier.regression(np.ascontiguousarray(sl[:, :stages[k].classifier.input_dim]))
+        clf = stages[k].classifier
+        x = np.ascontiguousarray(sl[:, :clf.input_dim])
+        dev_reg = clf.regression(x)
+        want = ref_c.gauss_regression(x.astype(np.float64), clf.means, clf.inv_covs, clf._sqrt_def_covs, clf.p, clf.avg_labels, want_std=False)
+        assert np.allclose(dev_reg, want, rtol=1e-9, atol=1e-9 * max(np.abs(want).max(), 1e-300)), (k, stages[k].name)
+        checked.append((k, len(x)))
+        return dev_reg              # the loop is fed the device value so that coordinates can be compared bit for bit
     ref = CR.run_cascade([s.name for s in stages], [s.flow is not None for s in stages], boxes, level, pipe, extract, execute, regress)
+    assert [k for k, _ in checked] == list(range(len(stages))) and all(n > 0 for _, n in checked)     # every stage, on real rows
     # survivor counts are read back after Disc stages only (-1 elsewhere: the count stays on the device)
-    known = [i for i, c in enumerate(got["counts"]) if c >= 0]
-    assert [stages[i].type for i in known] == ["Disc"] * len(known) and len(known) == 5
+    known = [i for i, c in enumerate(got["counts"]) if c >= 0 and stages[i].type == "Disc"]
+    assert len(known) == sum(s.type == "Disc" for s in stages)
     assert [got["counts"][i] for i in known] == [ref["counts"][i] for i in known], (got["counts"], ref["counts"])
     assert got["rows_executed"] >= ref["rows_executed"]        # launches between two Disc stages are sized by the last count read
     assert 0 < got["counts"][-1] < len(boxes) and got["counts"][0] < len(boxes)
     assert np.array_equal(got["orig_index"], ref["orig_index"])
     assert np.array_equal(got["coords"], ref["coords"]) and np.array_equal(got["angles"], ref["angles"])
     assert np.allclose(got["confidence"], ref["confidence"], rtol=1e-12, atol=1e-12)
-    assert np.abs(got["angles"]).max() > 0           # rotated extraction really took part
+    if any(s.type == "PAng" for s in stages[:-1]):
+        assert np.abs(got["angles"]).max() > 0       # rotated extraction really took part
     # the pieces the loop was fed: windows vs PIL's rule, features vs the oracle
     assert np.array_equal(subs0[::7], pil_restate.extract_subimages_rotate(frame, boxes[::7], np.zeros(len(boxes[::7])), (16, 16)))
     r = mdp_restate.execute_flow(nodes, subs0[::5])
     assert np.abs(feats[::5] - r).max() <= 1e-4 * np.abs(r).max()
     dc.close()
-    flow.close()
+    for f in flows:
+        f.close()
 
 
 @pytest.mark.gpu

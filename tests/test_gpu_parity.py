@@ -336,9 +336,12 @@ def test_full_size_properties(native_lib, nets):
 
 
 def test_gaussian_regression(native_lib):
-    """hg_gauss_regression on the parameters of three of the reference's own classifier files."""
+    """hg_gauss_regression on the parameters of seven of the reference's own classifier files — one per (classes, features)
+    shape of SavedClassifiers/*.pckl, the K = 50, d = 20 pose regressors (sqrt-determinants ~1e42) included; rows far from
+    every class and rows exactly on a class mean are part of the fixture (FaceDetectUpdated.py:709-719)."""
     g = np.load(os.path.join(GOLD, "classifiers.npz"))
-    for i in range(3):
+    assert int(g["n_classifiers"]) == 7
+    for i in range(7):
         clf = GaussianClassifier(g["c%d_means" % i], g["c%d_inv_covs" % i], g["c%d_sqrt_def_covs" % i], g["c%d_p" % i],
                                  avg_labels=g["c%d_avg_labels" % i])
         x = g["c%d_x" % i]

@@ -60,11 +60,17 @@ def test_numpy_and_c_restatements_agree(maker):
 
 def test_expansion_known_answers():
     x = np.array([[1.0, -2.0, 3.0], [0.0, 0.5, -4.0]])
-    node = N.GeneralExpansionNode([N.identity, N.unsigned_08expo, N.signed_08expo, N.QT, N.pair_prodsadj1_ex,
-                                   N.sel_exp(2, N.QT)], 3)
+    node = N.GeneralExpansionNode([N.identity, N.unsigned_08expo, N.signed_08expo, N.QT, N.pair_prodsadj_ex(1, "offset"),
+                                   N.sel_exp(2, N.QT), N.pair_prodsadj_ex(2, "band"), N.pair_prodsadj_ex(1, "band"),
+                                   N.sel_exp(2, N.pair_prodsadj_ex(2, "band"))], 3)
     y = oracle.execute_node(node, x)
     exp0 = np.array([1, -2, 3, 1, 2 ** 0.8, 3 ** 0.8, 1, -(2 ** 0.8), 3 ** 0.8,
-                     1, -2, 3, 4, -6, 9, -2, -6, 1, -2, 4])
+                     1, -2, 3, 4, -6, 9, -2, -6, 1, -2, 4,
+                     1, 4, 9, -2, -6,              # band of 2 offsets: squares, then x_i x_{i+1}
+                     1, 4, 9,                      # band of 1 offset: the squares alone
+                     1, 4, -2])                    # band of 2 over the first 2 columns
+    with pytest.raises(ValueError, match="reading"):
+        N.pair_prodsadj_ex(2, None)
     assert node.output_dim == exp0.size == y.shape[1]
     assert np.allclose(y[0], exp0, rtol=1e-15)
     assert y[1, 3] == 0.0 and y[1, 6] == 0.0              # 0 ** 0.8 == 0 exactly, signed too
@@ -133,7 +139,9 @@ def test_classifier_known_answers():
     """Reference-owned data: stored _sqrt_def_covs must equal det(inv_covs)^-1/2, and
     the log-domain regression equals MDP's linear-domain formula."""
     g = np.load(os.path.join(GOLD, "classifiers.npz"))
-    for i in range(3):
+    assert int(g["n_classifiers"]) == 7          # every (classes, features) shape of /root/reference/SavedClassifiers
+    assert sorted(g["c%d_means" % i].shape for i in range(7)) == [(2, 5), (10, 9), (39, 4), (39, 5), (50, 10), (50, 12), (50, 20)]
+    for i in range(7):
         means, ic, sd = g["c%d_means" % i], g["c%d_inv_covs" % i], g["c%d_sqrt_def_covs" % i]
         p, avg, x = g["c%d_p" % i], g["c%d_avg_labels" % i], g["c%d_x" % i]
         sign, logdet = np.linalg.slogdet(ic)

@@ -32,7 +32,8 @@ def _fake_modules():
                                   ("mdp.hinet", "Layer"), ("mdp.hinet", "CloneLayer"), ("mdp.hinet", "FlowNode"),
                                   ("igsfa_node", "iGSFANode"), ("mdp.linear_flows", "Flow"), ("more_nodes", "HeadNode"),
                                   ("more_nodes", "MysteryNode")]}
-    for fname in ("identity", "unsigned_08expo", "signed_08expo", "QT", "pair_prodsadj1_ex", "fancy_unknown_exp"):
+    for fname in ("identity", "unsigned_08expo", "signed_08expo", "QT", "pair_prodsadj1_ex", "pair_prodsadj2_ex", "pair_prodsadj3_ex",
+                  "fancy_unknown_exp"):
         def f(x):
             return x
         f.__name__ = f.__qualname__ = fname
@@ -59,9 +60,8 @@ def _to_fake(node, mods, C):
     if name == "LinearRegressionNode":
         return bag(C[name], beta=node.beta, **io)
     if name == "GeneralExpansionNode":
-        fn = {"identity": E.identity, "unsigned_08expo": E.unsigned_08expo, "signed_08expo": E.signed_08expo,
-              "QT": E.QT, "pair_prodsadj1_ex": E.pair_prodsadj1_ex}
-        return bag(C[name], funcs=[fn[f.__name__] for f in node.funcs], **io)
+        # a pickle holds the function's NAME only: both readings of pair_prodsadj{k}_ex come out as the same global
+        return bag(C[name], funcs=[getattr(E, f.__name__.split("[")[0]) for f in node.funcs], **io)
     if name in ("Switchboard", "Rectangular2dSwitchboard", "PInvSwitchboard"):
         return bag(C[name], connections=node.connections, **io)
     if name == "CloneLayer":
@@ -217,3 +217,42 @@ def test_unknown_classes_fail_loudly(tmp_path):
         pickle_import.load_flow_pickle(str(tmp_path / "a.pckl"))
     with pytest.raises(TypeError, match="unsupported expansion function"):
         pickle_import.load_flow_pickle(str(tmp_path / "b.pckl"))
+
+
+def _pair_net(reading, seed=3):
+    """Two layers whose expansions name pair_prodsadj{1,2,3}_ex, under one reading."""
+    from pyfaceanalysis_amd import nodes as N
+    rng = np.random.default_rng(seed)
+    funcs = [N.identity, N.pair_prodsadj_ex(2, reading), N.unsigned_08expo, N.pair_prodsadj_ex(1, reading), N.pair_prodsadj_ex(3, reading)]
+    sb0 = N.Rectangular2dSwitchboard((8, 8), (4, 4), (4, 4), 1)
+    l0 = []
+    for _ in range(4):
+        ex = N.GeneralExpansionNode(funcs, 7)
+        l0.append(N.FlowNode([helpers.rand_pca(rng, 16, 7, N.WhiteningNode), ex, helpers.rand_sfa(rng, ex.output_dim, 9)]))
+    sb1 = N.Rectangular2dSwitchboard((2, 2), (2, 2), (2, 2), 9)
+    ex = N.GeneralExpansionNode(funcs, 11)
+    l1 = [N.FlowNode([helpers.rand_pca(rng, 36, 11), ex, helpers.rand_sfa(rng, ex.output_dim, 21, N.GSFANode)])]
+    return [sb0, N.Layer(l0), sb1, N.Layer(l1)]
+
+
+@pytest.mark.parametrize("reading", ["offset", "band"])
+def test_pair_prodsadj_reading_must_be_stated(tmp_path, reading):
+    """The pickle names `pair_prodsadj2_ex`; whether that is x_i x_{i+2} or the reflexive band of offsets 0..1 is not
+    decidable here, so the importer refuses to pick: no default, like igsfa_lr_input."""
+    nodes = _pair_net(reading)
+    mods, C = _fake_modules()
+    path = _dump(tmp_path, nodes, mods, C)
+    with pytest.raises(ValueError, match="pair_prodsadj_reading"):
+        pickle_import.load_flow_pickle(path)
+    with pytest.raises(ValueError, match="pair_prodsadj_reading"):
+        pickle_import.pickle_to_blob(path, pair_prodsadj_reading="both")
+    got = pickle_import.load_flow_pickle(path, pair_prodsadj_reading=reading)
+    x = np.random.default_rng(0).normal(size=(9, 64)) * 3 + 100
+    assert np.array_equal(oracle.execute_flow(got, x), oracle.execute_flow(nodes, x))
+    back = blob_to_flow(pickle_import.pickle_to_blob(path, pair_prodsadj_reading=reading))
+    assert [f.kind for f in back[1].nodes[0].flow[1].funcs] == [f.kind for f in nodes[1].nodes[0].flow[1].funcs]
+    assert np.array_equal(oracle.execute_flow(back, x), oracle.execute_flow(nodes, x))
+    # the other reading has another width: the pickled output_dim exposes a wrong choice instead of converting silently
+    other = "band" if reading == "offset" else "offset"
+    with pytest.raises(ValueError, match="try the other reading"):
+        pickle_import.load_flow_pickle(path, pair_prodsadj_reading=other)

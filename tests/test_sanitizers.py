@@ -64,3 +64,21 @@ def test_blob_parser_under_asan_ubsan(tmp_path, nets):
     parsed = sum(int(l.split()[1]) for l in out.decode().splitlines() if l.startswith("parsed"))
     rejected = sum(int(l.split()[3]) for l in out.decode().splitlines() if l.startswith("parsed"))
     assert parsed + rejected == len(files) and parsed >= n_valid and rejected > 200
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_host_pool_under_tsan(tmp_path):
+    """The packing pool of the host path (hg_hostpool.hpp) under ThreadSanitizer: alternating 4-task and large regions back
+    to back from two caller threads (a worker still leaving the previous region took a ticket of the next one)."""
+    exe = tmp_path / "tsan_pool_driver"
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-pthread", "-I" + os.path.join(ROOT, "pyfaceanalysis_amd", "csrc"),
+           os.path.join(ROOT, "tests", "tsan_pool_driver.cpp"), "-o", str(exe)]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        pytest.skip("TSAN build not possible here: " + r.stdout.decode(errors="replace")[-300:])
+    r = subprocess.run([str(exe)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600,
+                       env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1:second_deadlock_stack=1"))
+    out = r.stdout.decode(errors="replace")
+    if "FATAL: ThreadSanitizer" in out and "unexpected memory mapping" in out:
+        pytest.skip("TSAN cannot run in this container (address-space layout): " + out[-200:])
+    assert r.returncode == 0 and "WARNING: ThreadSanitizer" not in out and "bad 0 0 thrown 1 sum 4950" in out, out[-3000:]

@@ -1,0 +1,127 @@
+"""GPU: the branch of pyfaceanalysis_amd.sharded.ShardedFlow that bench.py --gpus N runs on every rank — CUDA device,
+collective on: side stream, two feature buffers, events in both directions, RCCL all-gather — exercised on the one GPU a
+test box has by initialising the "nccl" (= RCCL) backend IN-PROCESS at world size 1 (tcp://127.0.0.1:<free port>, no
+launcher, no child process).  SURVEY.md §8e; rows are independent (FaceDetectUpdated.py:739-759), so the gathered
+matrix must hold, bit for bit, what Flow.execute gives for the same rows."""
+import socket
+
+import numpy as np
+import pytest
+
+from tests.conftest import get_net
+
+pytestmark = pytest.mark.gpu
+
+K = 20
+
+
+@pytest.fixture(scope="module")
+def rccl_world1(native_lib):
+    import torch
+    import torch.distributed as dist
+    assert torch.cuda.is_available()
+    torch.cuda.set_device(0)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    yield dist
+    dist.destroy_process_group()
+
+
+def _flow(preset="U11L-64"):
+    from pyfaceanalysis_amd import synth
+    from pyfaceanalysis_amd.flow import Flow
+    blob, nodes = synth.cached_preset_blob(preset)
+    return Flow.from_blob(blob, device=0, output_dtype=np.float32), nodes
+
+
+def test_collective_branch_matches_flow_execute(rccl_world1):
+    """>= 50 steps alternating both buffers, every step's gathered rows bit-equal to Flow.execute of the same block;
+    blocks change from step to step so a stale buffer would show."""
+    import torch
+    from pyfaceanalysis_amd import synth
+    from pyfaceanalysis_amd.sharded import ShardedFlow
+    flow, nodes = _flow()
+    rows = 333                                          # not a multiple of the 16-row tile
+    dev = torch.device("cuda", 0)
+    sf = ShardedFlow.for_flow(flow, K, rows, dev, collective=True)
+    assert sf.cuda and sf.collective and sf.world == 1 and sf.comm is not None
+    xs_host = [synth.make_subimages(rows, 64, seed=100 + i, dtype=np.float32) for i in range(3)]
+    want = [flow.execute(x.astype(np.float64))[:, :K].astype(np.float32) for x in xs_host]
+    xs = [torch.from_numpy(x).to(dev) for x in xs_host]
+    kept = []
+    for i in range(60):
+        y = sf.step(xs[i % 3])
+        ev = sf.done_event()
+        assert ev is not None and y.data_ptr() == sf.y_alls[i & 1].data_ptr()
+        if i % 7 == 0:                                  # honour the step's own event instead of a full wait()
+            ev.synchronize()
+            kept.append((i, y.clone()))
+        elif i % 5 == 0:
+            sf.wait()
+            kept.append((i, y.clone()))
+    sf.wait()
+    assert len(kept) >= 15
+    for i, y in kept:
+        assert np.array_equal(y.cpu().numpy(), want[i % 3]), "step %d" % i
+    with pytest.raises(ValueError):
+        sf.done_event(10)                               # that buffer was handed to step 12, 14, ... long ago
+    flow.close()
+
+
+def test_ragged_blocks_and_stale_rows(rccl_world1):
+    """The last block of a ragged batch is short: rows beyond it are published as zeros even when a fuller step
+    used the same buffer before (the buffers are reused); execute() slices to n_total."""
+    import torch
+    from pyfaceanalysis_amd import synth
+    from pyfaceanalysis_amd.sharded import ShardedFlow, shard_bounds
+    flow, nodes = _flow()
+    dev = torch.device("cuda", 0)
+    rows = 96
+    sf = ShardedFlow.for_flow(flow, K, rows, dev, collective=True)
+    x_host = synth.make_subimages(rows, 64, seed=7, dtype=np.float32)
+    want = flow.execute(x_host.astype(np.float64))[:, :K].astype(np.float32)
+    x = torch.from_numpy(x_host).to(dev)
+    for m in (96, 96, 17, 96, 0, 1, 96, 50):            # buffer 0: 96,17,0,96 ; buffer 1: 96,96,1,50
+        y = sf.step(x[:m])
+        sf.wait()
+        got = y.cpu().numpy()
+        assert np.array_equal(got[:m], want[:m]), m
+        assert not got[m:].any(), "rows beyond a %d-row block must be zero" % m
+    lo, hi, per = shard_bounds(77, 1, 0)
+    y = sf.execute(x[:77], n_total=77) if per <= rows else None
+    assert tuple(y.shape) == (77, K) and np.array_equal(y.cpu().numpy(), want[:77])
+    with pytest.raises(ValueError):
+        sf.step(torch.zeros((rows + 1, x.shape[1]), device=dev))
+    flow.close()
+
+
+def test_collective_step_costs_no_more_than_collective_free(rccl_world1):
+    """World-1 RCCL step time beside the collective-free one (the gather of step i runs under step i + 1): reported,
+    and bounded loosely — a serialised gather cost +39 us per 0.64 ms step in round 1."""
+    import time
+    import torch
+    from pyfaceanalysis_amd import synth
+    from pyfaceanalysis_amd.sharded import ShardedFlow
+    flow, nodes = _flow("U11L-128")
+    dev = torch.device("cuda", 0)
+    rows = 4096
+    x = torch.from_numpy(synth.make_subimages(rows, 128, dtype=np.float32)).to(dev)
+    res = {}
+    for name, coll in (("collective_free", False), ("rccl_world1", True), ("collective_free_again", False)):
+        sf = ShardedFlow.for_flow(flow, K, rows, dev, collective=coll)
+        for _ in range(300):
+            sf.step(x)
+        sf.wait()
+        t0 = time.perf_counter()
+        for _ in range(400):
+            sf.step(x)
+        sf.wait()
+        res[name] = (time.perf_counter() - t0) / 400 * 1e3
+    print("ShardedFlow.step, 4096 rows U11L-128, ms/step:", {k: round(v, 4) for k, v in res.items()})
+    base = min(res["collective_free"], res["collective_free_again"])
+    assert res["rccl_world1"] <= base * 1.10 + 0.02, res
+    flow.close()
