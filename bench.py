@@ -94,10 +94,16 @@ def cpu_baseline(nodes, n=256, reps=6):
 
 
 def frame_leg(flow, dev, reps=100, flow_factory=None):
+    return _frame_leg(flow, dev, reps, flow_factory)
+
+
+def _frame_leg(flow, dev, reps, flow_factory):
     """BASELINE.json configs[2] as an extra figure beside the headline: one synthetic 1920x1080 frame, smallest_face 0.1,
     prescaled to 1000x562 (FaceDetectUpdated.py:551-556) -> 10 pyramid levels / 1738 first-stage windows of 128x128, all
     levels as ONE batch, through the synthetic 17-stage face cascade (pyfaceanalysis_amd/synth_cascade.py: the pipeline's
-    stage structure, synthetic networks and classifiers), everything on the device: prescale, rotated window extraction,
+    stage structure; FOUR distinct synthetic networks in the roles of the pipeline's four face flows,
+    Pipelines/Pipeline_experimental.txt, each with its own handle, weights and workspace; Gaussian classifiers with the
+    class counts of the reference's files, 10 for Disc and 50 for the pose regressors), everything on the device: prescale, rotated window extraction,
     flow.execute, Gaussian regression, coordinate update, discard, compaction; the host reads one survivor count per stage.
     `first_stage_ms` is the chain extract -> execute -> regression over all 1738 windows with no host hop at all."""
     import torch
@@ -126,7 +132,28 @@ def frame_leg(flow, dev, reps=100, flow_factory=None):
         clf.regression_device(feats.data_ptr(), np.float32, n0, N_COLS, reg.data_ptr(), stream=st.cuda_stream)
     first_stage(boot.stages[0].classifier)
     torch.cuda.synchronize(dev)
-    stages = synth_cascade.build_face_cascade(flow, feats.cpu().numpy(), pipe, keep_fraction=0.1)
+    # three more networks of the same architecture (other seeds), trained on the GPU (< 1 s each): with `flow` they play the
+    # pipeline's four face flows (synth_cascade.FLOW_ROLE)
+    from pyfaceanalysis_amd.blob import flow_to_blob
+    from pyfaceanalysis_amd.flow import Flow
+    more_blobs = [flow_to_blob(synth.build_preset(PRESET, seed=synth.WEIGHT_SEED + 1009 * i, device=dev.index)) for i in (1, 2, 3)]
+
+    def four_flows(first):
+        fl = [first] + [Flow.from_blob(b, device=dev.index, output_dtype=np.float32) for b in more_blobs]
+        for f_ in fl:
+            f_.reserve(n0)
+        return fl
+
+    def calib(fl):       # first-stage features of this frame through every flow: the classifiers' calibration samples
+        out_ = []
+        for f_ in fl:
+            f_.execute_device(subs.data_ptr(), np.uint8, n0, SIDE * SIDE, feats.data_ptr(), np.float32, N_COLS, N_COLS, stream=st.cuda_stream)
+            torch.cuda.synchronize(dev)
+            out_.append(feats.cpu().numpy().copy())
+        return out_
+    flows4 = four_flows(flow)
+    feats4 = calib(flows4)
+    stages = synth_cascade.build_face_cascade(flows4, feats4, pipe, keep_fraction=0.1)
     dc = DeviceCascade(stages, (SIDE, SIDE), N_COLS, pipe)
     win = (boxes, level)
     for _ in range(3):
@@ -153,9 +180,8 @@ def frame_leg(flow, dev, reps=100, flow_factory=None):
         import threading
         extra = []
         for _ in range(3):
-            f2 = flow_factory()
-            f2.reserve(n0)
-            extra.append((f2, DeviceCascade(synth_cascade.build_face_cascade(f2, feats.cpu().numpy(), pipe, keep_fraction=0.1), (SIDE, SIDE), N_COLS, pipe)))
+            f2 = four_flows(flow_factory())
+            extra.append((f2, DeviceCascade(synth_cascade.build_face_cascade(f2, feats4, pipe, keep_fraction=0.1), (SIDE, SIDE), N_COLS, pipe)))
         cascades = [dc] + [c for _, c in extra]
         streams = [torch.cuda.Stream(dev) for _ in cascades]
         outs = [None] * len(cascades)
@@ -184,19 +210,150 @@ def frame_leg(flow, dev, reps=100, flow_factory=None):
             two[str(n_par)] = {"frames_per_s": n_par * reps / dtp, "same_survivor_counts_as_sequential": bool(same)}
         for f2, c2 in extra:
             c2.close()
-            f2.close()
+            for f_ in f2:
+                f_.close()
     res = {"frames_per_s": 1.0 / per_frame, "ms_per_frame": per_frame * 1e3, "frame": "1920x1080 synthetic, prescaled 1000x562, smallest_face 0.1",
            "levels": int(len(np.unique(level[:, 2]))), "windows": n0, "stages": len(stages), "rows_executed": int(out["rows_executed"]),
            "survivors_per_stage": [int(c) for c in out["counts"]], "detections": int(out["counts"][-1]),
            "detections_per_s": float(out["counts"][-1]) / per_frame,
            "first_stage_ms": e0.elapsed_time(e1) / reps,
+           "distinct_flow_handles": len({id(s_.flow) for s_ in stages if s_.flow is not None}),
+           "classifier_classes": sorted({int(s_.classifier.means.shape[0]) for s_ in stages}),
            "note": "synthetic networks and classifiers (trained flows are not shipped): timing only; host work per frame = "
                    "grid constants + 17 launches' worth of ctypes calls + one 4-byte count readback per stage"}
     if two is not None:
         res["frames_in_flight"] = two
     dc.close()
     boot.close()
+    for f_ in flows4[1:]:
+        f_.close()
     return res
+
+
+def host_path_leg(blob):
+    """The reference's actual call hands over HOST ndarrays (face_analysis.py:786 -> FaceDetectUpdated.py:699): time
+    hg_flow_execute — pack / narrow, H2D, all kernels, D2H, synchronous — on float64 (what images_asarray yields) and
+    uint8 batches of 4096 and 728 rows (728 = the largest single execute of a real 1080p frame).  Best of 5
+    after two warm-up calls.  `caller_GBps` = bytes of the caller's array per second (float64 rows holding integer pixel
+    values cross PCIe as uint8 after the exact narrowing, so this is NOT the PCIe rate)."""
+    from pyfaceanalysis_amd import synth
+    from pyfaceanalysis_amd.flow import Flow
+    out = {}
+    f = Flow.from_blob(blob, output_dtype=np.float64)
+    for dt in (np.float64, np.uint8):
+        for n in (4096, 728):
+            x = synth.make_subimages(n, SIDE, dtype=dt)
+            f.execute(x[:64], n_cols=N_COLS)
+            f.execute(x, n_cols=N_COLS)
+            best = 1e9
+            for _ in range(5):
+                t0 = time.perf_counter()
+                f.execute(x, n_cols=N_COLS)
+                best = min(best, time.perf_counter() - t0)
+            out["%s_n%d" % (np.dtype(dt).name, n)] = {"sub_images_per_s": n / best, "ms_per_call": best * 1e3, "caller_GBps": x.nbytes / best / 1e9}
+    f.close()
+    out["note"] = "Flow.execute(host ndarray) -> host float64 (N, 20): includes packing, H2D, kernels, D2H; never `value`"
+    return out
+
+
+def u11l_64_leg(dev, rows, steps):
+    """The shipped pipelines feed the face flows 64x64 sub-images (Pipelines/Pipeline_experimental.txt:2): the
+    same step on the U11L-64 preset, device resident, plus its error against the oracle on 64 rows."""
+    import torch
+    from oracle import mdp_restate
+    from pyfaceanalysis_amd import synth
+    from pyfaceanalysis_amd.flow import Flow
+    blob, nodes = synth.cached_preset_blob("U11L-64")
+    flow = Flow.from_blob(blob, device=dev.index, output_dtype=np.float32)
+    flow.reserve(rows)
+    xh = synth.make_subimages(rows, 64, dtype=np.float32)
+    x = torch.from_numpy(xh).to(dev)
+    y = torch.empty((rows, N_COLS), dtype=torch.float32, device=dev)
+    st = torch.cuda.current_stream(dev)
+
+    def run(k):
+        for _ in range(k):
+            flow.execute_device(x.data_ptr(), np.float32, rows, x.shape[1], y.data_ptr(), np.float32, N_COLS, N_COLS, stream=st.cuda_stream)
+        torch.cuda.synchronize(dev)
+    run(max(100, steps // 4))
+    t0 = time.perf_counter()
+    run(steps)
+    dt = (time.perf_counter() - t0) / steps
+    ref = mdp_restate.execute_flow(nodes, xh[:64].astype(np.float64))[:, :N_COLS]
+    err = float(np.abs(y[:64].cpu().numpy() - ref).max() / np.abs(ref).max())
+    fl = synth.flops_per_row(nodes)
+    flow.close()
+    return {"workload": "U11L-64 (11 layers, 64x64 sub-images, first 20 features), %d rows resident in HBM" % rows, "sub_images_per_s": rows / dt,
+            "ms_per_step": dt * 1e3, "flops_per_subimage": int(fl), "tflops": fl * rows / dt / 1e12, "max_rel_err_vs_oracle": err}
+
+
+def train_leg(dev, n=100_000):
+    """BASELINE.json configs[4]: one SFA training step — per-node mean / covariance / covariance of the time differences in
+    fp64, then the generalised symmetric eigen-solve — over 100 000 synthetic 128x128 patches (uint8, 1.64 GB resident),
+    layer-0 geometry (1024 nodes x 16 pixels); eigenvalues and B-normalised eigenvectors of three nodes against
+    scipy.linalg.eigh (budget 1e-5).  The sequence is a window gliding over a texture, as in tests/test_train_gpu.py."""
+    import scipy.linalg
+    import torch
+    from pyfaceanalysis_amd import nodes as N, synth
+    from pyfaceanalysis_amd.train import sfa_train_layer
+    rng = np.random.default_rng(3)
+    tex = torch.from_numpy(np.rint(synth._box3(rng.integers(0, 256, (SIDE + 600, SIDE + 600), dtype=np.uint8))).astype(np.uint8)).to(dev)
+    t = torch.arange(n, device=dev, dtype=torch.float64)
+    px = torch.round((0.5 + 0.5 * torch.sin(0.0021 * t)) * 599).long()
+    py = torch.round((0.5 + 0.5 * torch.sin(0.00153 * t + 1.0)) * 599).long()
+    x = torch.empty((n, SIDE * SIDE), dtype=torch.uint8, device=dev)
+    idx = torch.arange(SIDE, device=dev)
+    for i0 in range(0, n, 5000):
+        sl = slice(i0, min(n, i0 + 5000))
+        x[sl] = tex[(py[sl, None] + idx[None, :])[:, :, None], (px[sl, None] + idx[None, :])[:, None, :]].reshape(-1, SIDE * SIDE)
+    torch.cuda.synchronize(dev)
+    conn = N.Rectangular2dSwitchboard((SIDE, SIDE), (4, 4), (4, 4), 1).connections.reshape(-1, 16)
+    sfa_train_layer(x.data_ptr(), conn, device=dev.index, x_dtype=np.uint8, n=2000, ldx=SIDE * SIDE)        # warm-up (library handles)
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        ev, W, mu, tms = sfa_train_layer(x.data_ptr(), conn, device=dev.index, x_dtype=np.uint8, n=n, ldx=SIDE * SIDE)
+        wall = (time.perf_counter() - t0) * 1e3
+        if best is None or tms[0] + tms[1] < best[0] + best[1]:
+            best = (tms[0], tms[1], wall)
+    worst_val = worst_vec = 0.0
+    for k in (0, 517, 1023):
+        xk = x[:, torch.from_numpy(conn[k].astype(np.int64)).to(dev)].double().cpu().numpy()
+        B = np.cov(xk.T)
+        dx = xk[1:] - xk[:-1]
+        A = dx.T @ dx / (n - 1)
+        w, v = scipy.linalg.eigh(A, B)
+        worst_val = max(worst_val, float(np.abs(ev[k] / w - 1).max()))
+        worst_vec = max(worst_vec, float(np.abs(np.abs(np.diag(v.T @ B @ W[k])) - 1).max()))
+    del x
+    torch.cuda.empty_cache()
+    return {"workload": "configs[4]: %d patches of 128x128 uint8 resident in HBM, 1024 nodes x 16 inputs" % n, "statistics_ms": best[0],
+            "eigensolve_ms": best[1], "wall_ms": best[2], "input_GBps": n * SIDE * SIDE / best[0] / 1e6,
+            "statistics_gflops_f64": n * 1024.0 * (16 * 16 * 2) * 2 / best[0] / 1e6,
+            "max_rel_err_eigenvalues_vs_scipy": worst_val, "max_err_eigenvectors_vs_scipy": worst_vec, "nodes_checked": 3, "budget": 1e-5}
+
+
+def uniform_leg(flow, nodes, dev, rows, steps):
+    """SURVEY.md §8d's stress variant of the input: pure uniform random pixels (no 3x3 low-pass), same step, same checks."""
+    import torch
+    from oracle import mdp_restate
+    rng = np.random.default_rng(12345600)
+    xh = rng.integers(0, 256, (rows, SIDE * SIDE), dtype=np.uint8).astype(np.float32)
+    x = torch.from_numpy(xh).to(dev)
+    y = torch.empty((rows, N_COLS), dtype=torch.float32, device=dev)
+    st = torch.cuda.current_stream(dev)
+
+    def run(k):
+        for _ in range(k):
+            flow.execute_device(x.data_ptr(), np.float32, rows, x.shape[1], y.data_ptr(), np.float32, N_COLS, N_COLS, stream=st.cuda_stream)
+        torch.cuda.synchronize(dev)
+    run(50)
+    t0 = time.perf_counter()
+    run(steps)
+    dt = (time.perf_counter() - t0) / steps
+    ref = mdp_restate.execute_flow(nodes, xh[:64].astype(np.float64))[:, :N_COLS]
+    err = float(np.abs(y[:64].cpu().numpy() - ref).max() / np.abs(ref).max())
+    return {"input": "uniform random 0..255 per pixel", "sub_images_per_s": rows / dt, "ms_per_step": dt * 1e3, "max_rel_err_vs_oracle": err}
 
 
 def spawn_ranks(n_gpus, argv):
@@ -250,6 +407,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-frame", action="store_true", help="skip the configs[2] frame leg (frames_per_s)")
     ap.add_argument("--no-inflight", action="store_true", help="skip the batches-in-flight figure")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip host_path / u11l_64 / train_leg / uniform_input (figures beside the headline, outside the timed region)")
     ap.add_argument("--node-kind", default="pca_exp_sfa", choices=["pca_exp_sfa", "igsfa"],
                     help="node type of the synthetic 11-layer net (default: the BASELINE.md workload)")
     args = ap.parse_args()
@@ -414,6 +573,8 @@ def main():
         ref = mdp_restate.execute_flow(nodes, x_host[:m].astype(np.float64))[:, :N_COLS]
         got = y[:m].cpu().numpy().astype(np.float64)
         max_rel = float(np.abs(got - ref).max() / np.abs(ref).max())
+        # worst case per column over the first 20: each column against ITS OWN largest reference magnitude
+        per_col = np.abs(got - ref).max(axis=0) / np.abs(ref).max(axis=0)
 
         total_rows = rows * world
         value = total_rows * args.steps / elapsed
@@ -435,7 +596,8 @@ def main():
             kernels = []     # [name, ms, flops/row, bytes/row]
             for i, (nm, ms) in enumerate(stage_rows):
                 fl, by = per_layer[i] if (info.plan_kind == 1 and i < len(per_layer)) else (0, 0)
-                if kernels and ms < 0.02 and "fused in the same persistent kernel" in kernels[-1][0] and info.plan_kind == 1 and i < len(per_layer):
+                in_prev = kernels and ms < 0.02 and ("fused in the same persistent kernel" in kernels[-1][0] or "[in the top-of-hierarchy launch]" in nm)
+                if in_prev and info.plan_kind == 1 and i < len(per_layer):
                     kernels[-1][2] += fl
                     kernels[-1][3] += nodes_out_bytes[i] - nodes_out_bytes[i - 1]     # swap the intermediate output for the final one
                     kernels[-1][0] += " + " + nm.split(":")[0]
@@ -498,6 +660,9 @@ def main():
                        "settle_ms": round(settle_ms, 1), "rows_per_gpu": rows, "global_rows": total_rows, "plan": "fused" if info.plan_kind == 1 else "generic",
                        "parallelism": "row-shard x%d" % world},
             "max_rel_err_vs_oracle": max_rel,
+            "max_rel_err_first20_percol": {"worst": float(per_col.max()), "worst_column": int(per_col.argmax()),
+                                           "per_column": [float("%.3e" % v) for v in per_col], "rows_checked": m,
+                                           "definition": "max_i |y[i,c] - ref[i,c]| / max_i |ref[i,c]| per column c"},
             "flops_per_subimage": flops_row, "padded_flops_per_subimage": int(info.padded_flops_per_row),
             "roofline": roof,
         }
@@ -509,6 +674,12 @@ def main():
             if "frames_in_flight" in fr:
                 out["frames_per_s_4_in_flight"] = fr["frames_in_flight"]["4"]["frames_per_s"]
             out["frame_leg"] = fr
+        if not args.no_extra_legs and world == 1 and info.plan_kind == 1 and args.node_kind == "pca_exp_sfa" and rows == ROWS_PER_GPU:
+            leg_steps = max(50, min(args.steps, 400))
+            out["uniform_input"] = uniform_leg(flow, nodes, dev, rows, leg_steps)
+            out["u11l_64"] = u11l_64_leg(dev, rows, leg_steps)
+            out["host_path"] = host_path_leg(blob)
+            out["train_leg"] = train_leg(dev)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(nodes)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]

@@ -45,12 +45,11 @@ struct FusedOptions {
     // batches of up to this many 16-row tiles run the top layers as one persistent launch (0: never).  Measured on U11L-128
     // (tools/small_batch2.py): 5-10 % of a call up to N = 128, a loss from N = 340 (one workgroup per node and slice cannot
     // match the per-layer kernels' throughput), so the default stops at 8 tiles.
-    int chain_max_tiles = 0;      // HIGSFA_CHAIN_MAX_TILES: the persistent chain (k_chain) is off by default — since every small layer runs on
-                                  // k_stage_splitm, five such launches (42 us at N <= 128) beat the chain's one (52 us)
     bool no_pack = false;         // HIGSFA_NO_PACK: remainder tiles as whole blocks
     uint32_t wq_start = 0;        // HIGSFA_WQ_START: initial value of the tile-queue counters (tests: wrap-around)
     bool no_wgq = false;          // HIGSFA_NO_WGQ: k_stage01d with one tile queue per layer-1 node instead of one per chunk (2-3 % faster, +29 % HBM bytes)
     bool no_direct = false;       // HIGSFA_NO_DIRECT: front kernel always stages the input rows through LDS (k_stage01p)
+    int tail_max = 3;             // HIGSFA_TAIL: most layers k_tail fuses at the top of the hierarchy (0: off — per-layer launches + k_unpack)
     bool no_fspec = false;        // HIGSFA_NO_FSPEC: front kernel without the compile-time (identity, abs-power) expansion
     int splitm_max_nodes = 4;     // experiments: HIGSFA_SPLITM_MAX
     int splitm_max_wgs = 512;     // HIGSFA_SPLITM_WGS: largest k_stage_splitm grid for layers of more than splitm_max_nodes nodes
@@ -64,7 +63,7 @@ struct FusedOptions {
         o.no_prefetch_all = getenv("HIGSFA_NO_PREFETCH_ALL") != nullptr;
         if (const char* e = getenv("HIGSFA_STAMP")) o.stamp_stage = atoi(e);
         if (const char* e = getenv("HIGSFA_IG_SHAPE")) sscanf(e, "%d,%d", &o.ig_w, &o.ig_t);
-        if (const char* e = getenv("HIGSFA_CHAIN_MAX_TILES")) o.chain_max_tiles = std::max(0, atoi(e));
+
         o.no_pack = getenv("HIGSFA_NO_PACK") != nullptr;
         o.no_fspec = getenv("HIGSFA_NO_FSPEC") != nullptr;
         o.no_direct = getenv("HIGSFA_NO_DIRECT") != nullptr;
@@ -73,6 +72,7 @@ struct FusedOptions {
         if (const char* e = getenv("HIGSFA_SPLITM_MAX")) o.splitm_max_nodes = atoi(e);
         if (const char* e = getenv("HIGSFA_SPLITM_WGS")) o.splitm_max_wgs = atoi(e);
         if (const char* e = getenv("HIGSFA_SHAPES")) o.shape_variant = atoi(e);
+        if (const char* e = getenv("HIGSFA_TAIL")) o.tail_max = std::max(0, std::min(atoi(e), kMaxTail));
         return o;
     }
 };
@@ -1180,22 +1180,26 @@ public:
                << " blocks/tile";
             hs.name = os.str();
         }
-        plan_chain();
         fuse01_ = can_fuse01();
         if (fuse01_) {
             stages_[0].name += "  [+ stage 1 fused in the same persistent kernel when the input allows 16-byte loads]";
         }
         col_base_.resize(out_dim_);
+        col_of_.assign((size_t)std::max(prev_nb, 1) * 16, -1);      // inverse map for k_tail: (output block, feature of the tile) -> caller column
         for (int c = 0; c < out_dim_; ++c) {
             int q = prev_q[c];
             col_base_[c] = prev_blk[c] * 256 + (q & 3) * 64 + (q >> 2);
+            col_of_[(size_t)prev_blk[c] * 16 + q] = c;
         }
+        plan_tail();
     }
 
     int plan_kind() const override { return HG_PLAN_FUSED; }
     int n_stages() const override { return (int)stages_.size() + 1; }
     std::string stage_name(int i) const override {
-        return i < (int)stages_.size() ? stages_[i].name : std::string("fused unpack (fragment order -> row-major y)");
+        if (i < (int)stages_.size()) return stages_[i].name;
+        return tail_begin_ >= 0 ? std::string("row-major y written by the top-of-hierarchy launch (no unpack pass)")
+                                : std::string("fused unpack (fragment order -> row-major y)");
     }
     std::string describe() const override {
         std::ostringstream os;
@@ -1230,6 +1234,7 @@ public:
             }
         }
         d_col_base_.upload(col_base_.data(), col_base_.size() * 4);
+        d_col_of_.upload(col_of_.data(), col_of_.size() * 4);
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
@@ -1289,13 +1294,15 @@ public:
                 }
                 return R;
             };
-            if (chain_begin_ >= 0 && (int)si == chain_begin_ && n_tiles <= opt_.chain_max_tiles) {
-                run_chain(n_tiles, cur, nxt, st);           // reads `cur`, final layer writes `nxt`, the layers between their own regions
-                const int nc = (int)stages_.size() - chain_begin_;
-                std::swap(cur, nxt);
+            if (tail_begin_ >= 0 && (int)si == tail_begin_) {
+                // the top of the hierarchy as one launch that ends in the caller's rows (hg_fused_tail.hip)
+                TailParams TP = tail_params(cur, n_tiles, y, y_dtype, y_cols, ldy, n);
+                const int T = (n_tiles >= 512 && tail_waves(TP) <= 8) ? 2 : 1;
+                launch_tail(TP, T, st);
                 if (ev)
-                    for (int k = 0; k < nc; ++k) HG_HIP(hipEventRecord(ev[e++], st));   // first event carries the chain's time
-                break;
+                    for (size_t k = si; k <= stages_.size(); ++k) HG_HIP(hipEventRecord(ev[e++], st));   // the first event carries the launch's time
+                HG_HIP(hipGetLastError());
+                return;
             }
             StageParams P = base_params(s, cur, nxt);
             if (s.kind == 1) {        // row-major input -> fragment order
@@ -1642,8 +1649,6 @@ public:
     void release() override {
         bufA_.free();
         bufB_.free();
-        chain_buf_.free();
-        chain_flags_.free();
         wq_front_.ctr.free();
         wq_direct_.ctr.free();
         wq_direct_wg_.ctr.free();
@@ -1651,6 +1656,7 @@ public:
         err_host_ = nullptr;
         err_dev_ = nullptr;
         d_col_base_.free();
+        d_col_of_.free();
         for (auto& s : stages_) {
             s.d_afrag.free(); s.d_bias.free(); s.d_kb1tab.free(); s.d_chunks.free();
             s.d_runs.free(); s.d_piece.free(); s.d_koff.free(); s.d_kmean.free(); s.d_kcol.free(); s.d_gcol.free(); s.d_etab.free(); s.d_pack_slot.free();
@@ -2327,89 +2333,78 @@ private:
         hipLaunchKernelGGL(fn, (unsigned)blocks, nw * 64, lds_bytes, st, P);
     }
 
-    // The suffix of the stage list that k_chain (hg_fused_chain.hip) can run as one launch: ordinary layers of <= 16 nodes with
-    // one tile shape, at least two of them.
-    void plan_chain() {
-        chain_begin_ = -1;
-        if (opt_.chain_max_tiles <= 0 || stages_.size() < 3) return;
-        const HostStage& top = stages_.back();
-        int b = (int)stages_.size();
-        int sum_nodes = 0;
-        while (b > 1) {
+    // The suffix of the stage list that k_tail runs as one launch: ordinary layers (no remainder / packed tiles, K-blocks of the
+    // second affine within one load batch) whose widest one needs at most 16 waves — the 4-2-1 nodes at the top of the preset
+    // networks — and whose LDS tiles fit; the last layer always qualifies on its own when it is ordinary (then the launch is
+    // k_stage_splitm's work plus the row-major store).
+    void plan_tail() {
+        tail_begin_ = -1;
+        if (opt_.tail_max <= 0) return;
+        const int ns = (int)stages_.size();
+        int b = ns;
+        int act_blocks = 0, e_blocks = 0;
+        while (b > (fuse01_ ? 2 : 1) && ns - b < opt_.tail_max) {
             const HostStage& s = stages_[b - 1];
-            if (s.kind != 0 || s.from_x || s.rem4 || s.n_nodes > 16 || s.kb1 > 8 || s.nf > kMaxFuncs) break;
-            if (s.mt1 != top.mt1 || (s.has_exp ? s.mt2 : top.mt2) != top.mt2 || s.has_exp != top.has_exp) break;
-            if (chain_lds_bytes(s.node_blocks, s.bias_floats, s.mt1, std::max(1, s.nf)) > 150 * 1024) break;
-            if ((int)stages_.size() - (b - 1) > kMaxChain || sum_nodes + s.n_nodes > 128) break;
-            sum_nodes += s.n_nodes;
+            if (s.kind != 0 || s.from_x || s.rem4 || s.pack_out || s.nf > kMaxFuncs) break;
+            if (s.has_exp && s.mt1 * s.nf > 8) break;
+            const int waves = s.n_nodes * (s.has_exp ? std::max(s.mt1, s.mt2) : s.mt1);
+            if (waves > 16) break;
+            const int act = b - 1 < ns - 1 ? std::max(act_blocks, s.nb_out) : act_blocks;      // the last layer's output goes to y
+            const int eb = std::max(e_blocks, s.has_exp ? s.n_nodes * s.nf * s.mt1 : 0);
+            if (((size_t)2 * act + eb) * 1024 > 150 * 1024) break;
+            act_blocks = act;
+            e_blocks = eb;
             --b;
         }
-        if ((int)stages_.size() - b < 2 || !chain_supported(top.mt1, top.has_exp ? top.mt2 : top.mt1)) return;
-        chain_begin_ = b;
-        for (size_t i = b; i < stages_.size(); ++i) stages_[i].name += i == (size_t)b ? "  [small batches: this and the layers above run as one persistent launch]" : "  [in the persistent launch for small batches]";
+        if (b == ns) return;
+        tail_begin_ = b;
+        tail_act_blocks_ = act_blocks;
+        tail_e_blocks_ = e_blocks;
+        for (int i = b; i < ns; ++i)
+            stages_[i].name += i == b ? (ns - b > 1 ? "  [this and the layers above: ONE launch, activations in LDS, writes the caller's rows]"
+                                                    : "  [writes the caller's rows: no unpack pass]")
+                                      : "  [in the top-of-hierarchy launch]";
     }
 
-    void run_chain(int n_tiles, f32x4* cur, f32x4* nxt, hipStream_t st) {
-        const int nc = (int)stages_.size() - chain_begin_;
-        ChainParams C{};
-        C.n_stages = nc;
-        C.n_tiles = n_tiles;
-        C.tiles_per_group = 2;
-        C.n_groups = (n_tiles + 1) / 2;
-        int sum_nodes = 0;
-        size_t lds = 0, region = 0;
-        for (int k = 0; k < nc; ++k) sum_nodes += stages_[chain_begin_ + k].n_nodes;
-        C.slices = std::max(1, std::min(C.n_groups, n_cus_ / std::max(1, sum_nodes)));
-        // every layer but the last writes a region of its own
-        for (int k = 0; k + 1 < nc; ++k) region += (size_t)n_tiles * stages_[chain_begin_ + k].nb_out * 1024;
-        if (chain_buf_.bytes < region) chain_buf_.alloc(region);
-        const size_t fbytes = ((size_t)nc * C.n_groups * 16 + 16) * 4;
-        if (chain_flags_.bytes < fbytes) {
-            chain_flags_.alloc(fbytes * 2);
-            HG_HIP(hipMemset(chain_flags_.p, 0, chain_flags_.bytes));      // generation 0 is never published
-        }
-        C.flags = (uint32_t*)chain_flags_.p + 16;
-        C.err = device_error_word();
-        C.gen = ++chain_gen_;
-        if (chain_gen_ == 0xffffffffu) {      // wrap: start over with clean flags
-            HG_HIP(hipMemsetAsync(chain_flags_.p, 0, chain_flags_.bytes, st));
-            chain_gen_ = 0;
-            C.gen = ++chain_gen_;
-        }
-        f32x4* final_out = nxt;       // never the buffer the chain's first layer still reads
-        char* reg = (char*)chain_buf_.p;
-        const f32x4* in = cur;
-        int wg = 0;
-        for (int k = 0; k < nc; ++k) {
-            HostStage& hs = stages_[chain_begin_ + k];
-            ChainStage& S = C.st[k];
+    TailParams tail_params(const f32x4* in, int n_tiles, void* y, int y_dtype, int64_t y_cols, int64_t ldy, int64_t n) {
+        TailParams TP{};
+        const int ns = (int)stages_.size();
+        TP.n_stages = ns - tail_begin_;
+        for (int k = 0; k < TP.n_stages; ++k) {
+            HostStage& hs = stages_[tail_begin_ + k];
+            TailStage& S = TP.st[k];
             S.afrag = (const f32x4*)hs.d_afrag.p;
             S.bias = (const float*)hs.d_bias.p;
             S.kb1tab = (const int2*)hs.d_kb1tab.p;
-            S.in = in;
-            S.out = k + 1 < nc ? (f32x4*)reg : final_out;
             S.n_nodes = hs.n_nodes;
             S.kb1 = hs.kb1;
             S.nf = hs.nf;
             S.has_exp = hs.has_exp ? 1 : 0;
             S.node_blocks = hs.node_blocks;
             S.bias_floats = hs.bias_floats;
-            S.nb_in = hs.nb_in;
             S.nb_out = hs.nb_out;
             S.mto = hs.mto;
-            S.wg_begin = wg;
+            S.mt1 = hs.mt1;
+            S.mt2 = hs.mt2;
             for (int fi = 0; fi < hs.nf; ++fi) {
                 S.funcp |= (uint32_t)hs.funcs[fi].kind << (4 * fi);
                 S.expo[fi] = (float)hs.funcs[fi].expo;
                 for (int mt1 = 0; mt1 < hs.mt1; ++mt1) S.nk2p[mt1] |= (uint32_t)hs.nk2[mt1][fi] << (4 * fi);
             }
-            wg += hs.n_nodes * C.slices;
-            lds = std::max(lds, chain_lds_bytes(hs.node_blocks, hs.bias_floats, hs.mt1, std::max(1, hs.nf)));
-            in = (const f32x4*)reg;
-            reg += (size_t)n_tiles * hs.nb_out * 1024;
         }
-        const HostStage& top = stages_.back();
-        launch_chain(C, top.mt1, top.has_exp ? top.mt2 : top.mt1, wg, lds, st);
+        TP.in = in;
+        TP.y = y;
+        TP.col_of = (const int32_t*)d_col_of_.p;
+        TP.ldy = ldy;
+        TP.n_rows = n;
+        TP.y_cols = (int32_t)y_cols;
+        TP.y_f64 = y_dtype == HG_F64 ? 1 : 0;
+        if (y_dtype != HG_F32 && y_dtype != HG_F64) fail(HG_ERR_ARG, "output dtype must be f32 or f64");
+        TP.n_tiles = n_tiles;
+        TP.nb_in = stages_[tail_begin_].nb_in;
+        TP.act_blocks = tail_act_blocks_;
+        TP.e_blocks = tail_e_blocks_;
+        return TP;
     }
 
     // Layers 0 and 1 can share one kernel when a wave's two layer-0 node slots are exactly the two
@@ -2437,8 +2432,10 @@ private:
     int out_dim_;
     bool s0_transpose_ = false, fuse01_ = false;
     std::vector<HostStage> stages_;
-    std::vector<int32_t> col_base_;
-    DevBuf d_col_base_, bufA_, bufB_, stamp_buf_;
+    std::vector<int32_t> col_base_, col_of_;
+    DevBuf d_col_base_, d_col_of_, bufA_, bufB_, stamp_buf_;
+    int tail_begin_ = -1;         // first stage of the top-of-hierarchy launch (k_tail); -1: none
+    int tail_act_blocks_ = 0, tail_e_blocks_ = 0;
     WorkQueue wq_front_, wq_direct_, wq_direct_wg_;
     int32_t* err_host_ = nullptr;
     int32_t* err_dev_ = nullptr;
@@ -2447,9 +2444,7 @@ private:
     std::map<std::tuple<const void*, int, size_t>, int> occ_;
     int max_nb_ = 0;
     int64_t padded_flops_ = 0, cap_rows_ = 0;
-    int chain_begin_ = -1, n_cus_ = 256;      // first stage of the persistent top-of-hierarchy launch (-1: none)
-    uint32_t chain_gen_ = 0;
-    DevBuf chain_buf_, chain_flags_;
+    int n_cus_ = 256;
 };
 
 }  // namespace

@@ -105,7 +105,7 @@ __device__ __forceinline__ f32x4 pow_abs4(f32x4 z, float p) {
 //    FASTER that way than with the branches below (straight-line code between the MFMA runs schedules better; the
 //    transcendental unit is otherwise idle);
 //  * apply_func_uniform: identity costs nothing, one v_log + v_exp per value behind a real scalar branch (the empty asm
-//    statement cannot be speculated); the latency-bound small kernels (k_stage_splitm, k_chain) gain 10 % from it.
+//    statement cannot be speculated); the latency-bound small kernels (k_stage_splitm, k_tail) gain 10 % from it.
 __device__ __forceinline__ f32x4 apply_func(int func, float expo, f32x4 z) {
     f32x4 e;
     if (func == (int)E_IDENTITY) {
@@ -310,28 +310,32 @@ __device__ __forceinline__ void node_tail(const StageParams& P, WP wA2, BP b2, i
 }
 
 
-// k_chain (hg_fused_chain.hip): the layers at the top of the hierarchy as one persistent launch
-struct ChainStage {
+// k_tail (hg_fused_tail.hip): the LAST one to three layers of the hierarchy (1 / 2+1 / 4+2+1 nodes in the preset nets) as one
+// launch in which a workgroup takes T batch tiles through all of them, activations in LDS, and writes the caller's
+// row-major y (first y_cols columns) straight from the accumulators — no k_unpack pass, and only the output tiles that
+// hold a requested column are computed in the last node's second affine.
+struct TailStage {
     const f32x4* afrag;
     const float* bias;
     const int2* kb1tab;
-    const f32x4* in;
-    f32x4* out;
-    int32_t n_nodes, kb1, nf, has_exp, node_blocks, bias_floats, nb_in, nb_out, mto, wg_begin;
+    int32_t n_nodes, kb1, nf, has_exp, node_blocks, bias_floats, nb_out, mto, mt1, mt2;
     uint32_t nk2p[kMaxMT], funcp;
     float expo[kMaxFuncs];
 };
-constexpr int kMaxChain = 6;
-struct ChainParams {
-    ChainStage st[kMaxChain];
-    int32_t n_stages, n_tiles, tiles_per_group, n_groups, slices;
-    uint32_t gen;
-    uint32_t* flags;      // [stage][group][16]: generation number of the launch that published (stage, group, node)
-    int32_t* err;
+constexpr int kMaxTail = 3;
+struct TailParams {
+    TailStage st[kMaxTail];
+    const f32x4* in;          // input of the first fused layer, fragment order (global memory)
+    void* y;                  // caller's row-major output
+    const int32_t* col_of;    // [output block of the last layer][16 features] -> caller column, -1 = none
+    int64_t ldy, n_rows;
+    int32_t y_cols, y_f64;
+    int32_t n_stages, n_tiles, nb_in;
+    int32_t act_blocks, e_blocks;      // LDS: two activation buffers of act_blocks x T KiB, one expansion buffer of e_blocks x T KiB
 };
-bool chain_supported(int mt1, int mt2);
-size_t chain_lds_bytes(int node_blocks, int bias_floats, int mt1, int nf);
-void launch_chain(const ChainParams& C, int mt1, int mt2, int grid, size_t lds, hipStream_t st);
+size_t tail_lds_bytes(const TailParams& P, int T);
+int tail_waves(const TailParams& P);
+void launch_tail(const TailParams& P, int T, hipStream_t st);
 
 typedef void (*StageFn)(StageParams);
 typedef void (*StageFn2)(StageParams, StageParams);
@@ -352,7 +356,7 @@ void launch_im2frag(const void* x, int x_dtype, int64_t ldx, int64_t n_rows, int
 // 4 consecutive input elements -> 4 floats (16-byte / 4-byte / 32-byte loads)
 template <typename XT> struct Vec4Load;
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-constexpr int kBufferFlags = 0x00020000;      // raw buffer, 32-bit data format (as hg_fused_chain.hip)
+constexpr int kBufferFlags = 0x00020000;      // raw buffer, 32-bit data format
 template <> struct Vec4Load<float> {
     static __device__ __forceinline__ f32x4 ld(const float* p) { return *(const f32x4*)p; }
     // same through a buffer resource: scalar base, 32-bit byte offset per lane, out-of-range reads return 0

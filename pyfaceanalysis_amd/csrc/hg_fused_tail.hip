@@ -1,0 +1,228 @@
+// k_tail: the top of the hierarchy — the last one to three ordinary layers (4, 2, 1 nodes in the 11-layer nets) — as ONE
+// launch, ending in the caller's row-major y.
+//
+// Why: at the top there is next to no arithmetic left (layers 8-10 of U11L-128 hold 1.8 % of the FLOPs) and a launch is all
+// latency: start, one round of weight / input loads, two short dependent MFMA chains with an LDS exchange between them,
+// store, end — 7-14 us per layer whatever the batch, plus 5 us for the k_unpack pass that turned fragment order into the
+// caller's rows (profiles/r02_summary.md: 37 us for 0.83 GFLOP).  Here a workgroup of (nodes of the widest fused layer) x
+// (m-tiles) waves takes T batch tiles through all fused layers: wave w is (node, m-tile) of the layer it is working on, like
+// k_stage_splitm (hg_fused.hip), every weight block is read by exactly one wave straight from L2, the activations between
+// the layers stay in LDS in fragment order, and the last layer's accumulators go straight to y[:, :y_cols] — of the last
+// node's second affine only the output tiles that hold a requested column are computed (the caller reads sl[:, 0:k],
+// FaceDetectUpdated.py:709-719).
+//
+// Same products in the same order as k_stage / k_stage_splitm (bias first, K-blocks and k-steps ascending), so a network gives
+// the same bits whichever of the kernels runs its top layers.
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <utility>
+
+#include "hg_fused_dev.hpp"
+
+namespace hg {
+namespace fused {
+
+namespace {
+
+constexpr int KB = 8;      // K-blocks loaded per batch (all of a 120-input node's)
+
+// One layer for this workgroup's T tiles.  FIRST: inputs come from global memory (P.in), else from the LDS buffer `src`.
+// LAST: outputs go to the caller's y, else to the LDS buffer `dst` (block-major: block b of tile t at (b * T + t) * 64).
+template <int T, bool FIRST, bool LAST>
+__device__ __forceinline__ void tail_layer(const TailParams& P, const TailStage& S, const f32x4* src, f32x4* dst, f32x4* ebuf,
+                                           const int (&tile)[T], const uint32_t (&trow)[T], int w, int lane) {
+    const int g = lane >> 4;
+    const int wpn = S.has_exp ? (S.mt1 > S.mt2 ? S.mt1 : S.mt2) : S.mt1;      // waves per node
+    const int node = w / wpn, mw = w - node * wpn;
+    const bool on = node < S.n_nodes;
+    const f32x4* wnode = S.afrag + (size_t)(on ? node : 0) * S.node_blocks * 64 + lane;
+    const float* bnode = S.bias + (size_t)(on ? node : 0) * S.bias_floats + g * 4;
+    const int2* kt = S.kb1tab + (size_t)(on ? node : 0) * S.kb1;
+    const int nf = S.nf, mt1n = S.mt1, mt2n = S.mt2;
+    const int out_blk = node * S.mto + mw;
+    // which caller column each of this lane's four values of the output tile goes to (LAST only)
+    int col[4] = {-1, -1, -1, -1};
+    bool need_out = true;
+    if constexpr (LAST) {
+        const bool emits = on && mw < (S.has_exp ? mt2n : mt1n);
+        bool mine = false;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (emits) col[r] = P.col_of[out_blk * 16 + 4 * r + g];
+            if (col[r] >= P.y_cols) col[r] = -1;
+            mine |= col[r] >= 0;
+        }
+        need_out = __builtin_amdgcn_ballot_w64(mine) != 0;       // a tile without a requested column is not computed
+    }
+    auto emit = [&](const f32x4 (&v)[T]) {
+        if constexpr (LAST) {
+            const int j = lane & 15;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int64_t row = (int64_t)tile[t] * 16 + j;
+                if (tile[t] < P.n_tiles && row < P.n_rows) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (col[r] >= 0) {
+                            if (P.y_f64) ((double*)P.y)[row * P.ldy + col[r]] = (double)v[t][r];
+                            else ((float*)P.y)[row * P.ldy + col[r]] = v[t][r];
+                        }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < T; ++t) dst[((size_t)out_blk * T + t) * 64 + lane] = v[t];
+        }
+    };
+    const bool g1 = on && mw < mt1n && (S.has_exp || need_out);
+    const bool g2 = on && S.has_exp && mw < mt2n && need_out;
+    // GEMM-2 weights of this wave's output tile do not depend on z: fetch them first
+    f32x4 a2[KB];
+    const int k2n = mt1n * nf;
+    if (g2) {
+#pragma unroll
+        for (int k = 0; k < KB; ++k)
+            if (k < k2n) a2[k] = wnode[((size_t)S.kb1 * mt1n + (size_t)k * mt2n + mw) * 64];
+    }
+    if (g1) {
+        f32x4 z[T];
+        const f32x4 bb = *(const f32x4*)(bnode + mw * 16);
+#pragma unroll
+        for (int t = 0; t < T; ++t) z[t] = bb;
+        for (int k0 = 0; k0 < S.kb1; k0 += KB) {
+            f32x4 a1[KB], bf[KB][T];
+            int nks[KB];
+#pragma unroll
+            for (int k = 0; k < KB; ++k) {
+                nks[k] = 0;
+                if (k0 + k < S.kb1) {
+                    const int2 e = kt[k0 + k];
+                    nks[k] = e.y;
+                    a1[k] = wnode[((size_t)(k0 + k) * mt1n + mw) * 64];
+#pragma unroll
+                    for (int t = 0; t < T; ++t) {
+                        if constexpr (FIRST) bf[k][t] = P.in[(size_t)(trow[t] + e.x) * 64 + lane];
+                        else bf[k][t] = src[((size_t)e.x * T + t) * 64 + lane];
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < KB; ++k) {
+                const int nk = nks[k] & 255, r0 = nks[k] >> 8;      // (r0 > 0: a packed remainder block of the layer below)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (r >= r0 && r < nk) {
+#pragma unroll
+                        for (int t = 0; t < T; ++t) z[t] = MFMA16(a1[k][r], bf[k][t][r], z[t]);
+                    }
+            }
+        }
+        if (!S.has_exp) {
+            emit(z);
+        } else {
+            for (int fi = 0; fi < nf; ++fi) {
+                const int fk = (S.funcp >> (4 * fi)) & 15;
+                const float ex = S.expo[fi];
+#pragma unroll
+                for (int t = 0; t < T; ++t) ebuf[((((size_t)node * nf + fi) * mt1n + mw) * T + t) * 64 + lane] = apply_func_uniform(fk, ex, z[t]);
+            }
+        }
+    }
+    __syncthreads();                 // expanded tiles of every node are in LDS (a linear layer passes straight through)
+    if (g2) {
+        f32x4 y[T];
+        const f32x4 bb = *(const f32x4*)(bnode + (mt1n + mw) * 16);
+#pragma unroll
+        for (int t = 0; t < T; ++t) y[t] = bb;
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+            if (k >= k2n) continue;
+            const int mt1 = k / nf, fi = k - mt1 * nf;
+            const int nk = (S.nk2p[mt1] >> (4 * fi)) & 15;
+            f32x4 e[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) e[t] = ebuf[((((size_t)node * nf + fi) * mt1n + mt1) * T + t) * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (r < nk) {
+#pragma unroll
+                    for (int t = 0; t < T; ++t) y[t] = MFMA16(a2[k][r], e[t][r], y[t]);
+                }
+        }
+        emit(y);
+    }
+    if constexpr (!LAST) __syncthreads();      // this layer's output tiles are in LDS; ebuf is free again
+}
+
+template <int T, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) k_tail(TailParams P) {
+    extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int tile[T];
+    uint32_t trow[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        tile[t] = blockIdx.x * T + t;
+        trow[t] = (uint32_t)(tile[t] < P.n_tiles ? tile[t] : tile[0]) * (uint32_t)P.nb_in;
+    }
+    f32x4* act0 = smem;
+    f32x4* act1 = smem + (size_t)P.act_blocks * T * 64;
+    f32x4* ebuf = act1 + (size_t)P.act_blocks * T * 64;
+    if (P.n_stages == 1) {
+        tail_layer<T, true, true>(P, P.st[0], nullptr, nullptr, ebuf, tile, trow, w, lane);
+    } else if (P.n_stages == 2) {
+        tail_layer<T, true, false>(P, P.st[0], nullptr, act0, ebuf, tile, trow, w, lane);
+        tail_layer<T, false, true>(P, P.st[1], act0, nullptr, ebuf, tile, trow, w, lane);
+    } else {
+        tail_layer<T, true, false>(P, P.st[0], nullptr, act0, ebuf, tile, trow, w, lane);
+        tail_layer<T, false, false>(P, P.st[1], act0, act1, ebuf, tile, trow, w, lane);
+        tail_layer<T, false, true>(P, P.st[2], act1, nullptr, ebuf, tile, trow, w, lane);
+    }
+}
+
+template <int T>
+void launch_t(const TailParams& P, int waves, unsigned grid, size_t lds, hipStream_t st) {
+    auto go = [&](auto fn) {
+        if (lds > 64 * 1024) {      // raise the dynamic-LDS limit once per (device, function)
+            static thread_local std::map<std::pair<int, const void*>, size_t> raised;
+            int dev = 0;
+            HG_HIP(hipGetDevice(&dev));
+            size_t& have = raised[{dev, (const void*)fn}];
+            if (have < lds) {
+                HG_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                have = lds;
+            }
+        }
+        hipLaunchKernelGGL(fn, grid, waves * 64, lds, st, P);
+    };
+    if (waves <= 4) go(k_tail<T, 4>);
+    else if (waves <= 8) go(k_tail<T, 8>);
+    else go(k_tail<T, 16>);
+}
+
+}  // namespace
+
+int tail_waves(const TailParams& P) {
+    int wv = 1;
+    for (int s = 0; s < P.n_stages; ++s) {
+        const TailStage& S = P.st[s];
+        wv = std::max(wv, S.n_nodes * (S.has_exp ? std::max(S.mt1, S.mt2) : S.mt1));
+    }
+    return wv <= 4 ? 4 : wv <= 8 ? 8 : 16;
+}
+
+size_t tail_lds_bytes(const TailParams& P, int T) { return ((size_t)2 * P.act_blocks + P.e_blocks) * T * 1024; }
+
+void launch_tail(const TailParams& P, int T, hipStream_t st) {
+    const int waves = tail_waves(P);
+    const unsigned grid = (unsigned)((P.n_tiles + T - 1) / T);
+    const size_t lds = tail_lds_bytes(P, T);
+    if (T == 2) launch_t<2>(P, waves, grid, lds, st);
+    else launch_t<1>(P, waves, grid, lds, st);
+    HG_HIP(hipGetLastError());
+}
+
+}  // namespace fused
+}  // namespace hg

@@ -74,6 +74,34 @@ def train_apply(x_ptr, x_dtype, n, ldx, conn, mean, W, funcs, out_ptr, ldo, devi
                                                   vp(expos) if len(funcs) else None, C.c_void_p(int(out_ptr)), int(ldo), int(device)))
 
 
+def train_layer_device(x, conn, p, s, funcs, device=0):
+    """One layer of ``train_hierarchy_device``: per node whitening PCA (top ``p``), expansion by ``funcs``
+    (element-wise ``nodes.ExpFunc``), SFA (slowest ``s``), everything on the GPU.  ``x``: (T, D) float64 torch tensor on
+    the device in time order, ``conn``: (n_nodes, d_in) input columns.  Returns (mu, v, mue, sf, y): PCA means and
+    whitening matrices, SFA means and matrices (host arrays, sign convention of ``synth._sign_fix``) and the layer's
+    output (T, n_nodes * s) as a device tensor."""
+    import torch
+    from . import synth
+    kind_of = {"identity": 0, "abs_pow": 1, "signed_pow": 2}
+    T = x.shape[0]
+    n_nodes = conn.shape[0]
+    lam, vec, mu, _ = pca_train_layer(x.data_ptr(), np.float64, T, x.shape[1], conn, device)
+    lam, vec = lam[:, ::-1][:, :p], vec[:, :, ::-1][:, :, :p]
+    vec = synth._sign_fix(vec)
+    lam = np.maximum(lam, 1e-9 * lam[:, :1])
+    v = vec / np.sqrt(lam)[:, None, :]
+    width = sum(f.out_dim(p) for f in funcs)
+    e = torch.empty((T, n_nodes * width), dtype=torch.float64, device=x.device)
+    train_apply(x.data_ptr(), np.float64, T, x.shape[1], conn, mu, v, [(kind_of[f.kind], f.expo) for f in funcs], e.data_ptr(), e.shape[1], device)
+    # SFA on the expanded signal
+    conn_e = np.arange(n_nodes * width, dtype=np.int32).reshape(n_nodes, width)
+    _lam2, W, mue, _ = sfa_train_layer(e.data_ptr(), conn_e, device=device, x_dtype=np.float64, n=T, ldx=e.shape[1])
+    sf = synth._sign_fix(W[:, :, :s])
+    y = torch.empty((T, n_nodes * s), dtype=torch.float64, device=x.device)
+    train_apply(e.data_ptr(), np.float64, T, e.shape[1], conn_e, mue, sf, [], y.data_ptr(), y.shape[1], device)
+    return mu, v, mue, sf, y
+
+
 def train_hierarchy_device(side, f0, layer_dims, n_train=1500, seed=None, expo=0.8, layout="flownode", device=0, verbose=False):
     """``synth.train_hierarchy`` (node_kind "pca_exp_sfa") with the training set resident on the GPU: per layer the node
     statistics (covariance, difference covariance: HIP kernels, fp64 accumulation), the eigen-solves (PCA on (Cov, I), SFA on
@@ -88,7 +116,6 @@ def train_hierarchy_device(side, f0, layer_dims, n_train=1500, seed=None, expo=0
     T = x.shape[0]
     grid = None
     flow, ch = [], 1
-    kind_of = {"identity": 0, "abs_pow": 1, "signed_pow": 2}
     for li, (p, s) in enumerate(layer_dims):
         if li == 0:
             sb = N.Rectangular2dSwitchboard((side, side), (f0, f0), (f0, f0), 1)
@@ -106,21 +133,8 @@ def train_hierarchy_device(side, f0, layer_dims, n_train=1500, seed=None, expo=0
         conn = sb.connections.reshape(n_nodes, d_in)
         p_ = min(p, d_in)
         s_ = min(s, 2 * p_)
-        # whitening PCA
-        lam, vec, mu, _ = pca_train_layer(x.data_ptr(), np.float64, T, x.shape[1], conn, device)
-        lam, vec = lam[:, ::-1][:, :p_], vec[:, :, ::-1][:, :, :p_]
-        vec = synth._sign_fix(vec)
-        lam = np.maximum(lam, 1e-9 * lam[:, :1])
-        v = vec / np.sqrt(lam)[:, None, :]
         funcs = [N.identity, N.unsigned_expo(expo) if expo != 0.8 else N.unsigned_08expo]
-        e = torch.empty((T, n_nodes * 2 * p_), dtype=torch.float64, device=dev)
-        train_apply(x.data_ptr(), np.float64, T, x.shape[1], conn, mu, v, [(kind_of[f.kind], f.expo) for f in funcs], e.data_ptr(), e.shape[1], device)
-        # SFA on the expanded signal
-        conn_e = np.arange(n_nodes * 2 * p_, dtype=np.int32).reshape(n_nodes, 2 * p_)
-        _lam2, W, mue, _ = sfa_train_layer(e.data_ptr(), conn_e, device=device, x_dtype=np.float64, n=T, ldx=e.shape[1])
-        sf = synth._sign_fix(W[:, :, :s_])
-        y = torch.empty((T, n_nodes * s_), dtype=torch.float64, device=dev)
-        train_apply(e.data_ptr(), np.float64, T, e.shape[1], conn_e, mue, sf, [], y.data_ptr(), y.shape[1], device)
+        mu, v, mue, sf, y = train_layer_device(x, conn, p_, s_, funcs, device)
         pcas = [N.WhiteningNode(mu[k], v[k]) for k in range(n_nodes)]
         exps = [N.GeneralExpansionNode(funcs, p_) for _ in range(n_nodes)]
         sfas = [N.SFANode(mue[k], sf[k]) for k in range(n_nodes)]
@@ -131,7 +145,6 @@ def train_hierarchy_device(side, f0, layer_dims, n_train=1500, seed=None, expo=0
         flow.append(sb)
         flow.extend(layer)
         x, ch = y, s_
-        del e
         if verbose:
             print("  L%-2d grid %-7s nodes %4d  d_in %3d -> %3d   out std %.3f" % (li, grid, n_nodes, d_in, s_, float(x.std())))
         if n_nodes == 1 and li < len(layer_dims) - 1:

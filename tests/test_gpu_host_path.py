@@ -6,6 +6,7 @@ import pytest
 from oracle import mdp_restate as oracle
 from pyfaceanalysis_amd import synth
 from pyfaceanalysis_amd.flow import Flow
+from tests import helpers
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -116,32 +117,66 @@ def test_batch_size_dependence_is_bounded(native_lib, nets, monkeypatch):
     generic.close()
 
 
-def test_persistent_top_of_hierarchy_launch(native_lib, nets, monkeypatch):
-    """With HIGSFA_CHAIN_MAX_TILES set, small batches (N <= 128) run the last layers of U11L-128 (16, 8, 4, 2, 1 nodes) as ONE persistent launch whose
-    workgroups hand tile groups from layer to layer through memory (hg_fused_chain.hip).  Same bits as the per-layer
-    kernels; flags carry a generation number, so repeated calls and alternating batch sizes never see a stale hand-off."""
+def test_top_of_hierarchy_launch(native_lib, nets, monkeypatch):
+    """The last layers of U11L-128 (4, 2, 1 nodes) run as ONE launch that keeps the activations in LDS and writes the
+    caller's rows itself (k_tail, hg_fused_tail.hip; HIGSFA_TAIL = how many layers it may fuse, 0 = per-layer launches +
+    k_unpack).  Same products in the same order as the per-layer kernels: bit-identical features for every fusion depth,
+    batch size, column count, output dtype and row stride."""
     nodes = nets("U11L-128")
-    x = synth.make_subimages(300, 128, dtype=np.uint8)
-    monkeypatch.setenv("HIGSFA_CHAIN_MAX_TILES", "8")        # (off by default since the small layers run on k_stage_splitm)
-    chain = Flow(nodes, output_dtype=np.float32)
-    assert "one persistent launch" in chain.describe()
-    monkeypatch.delenv("HIGSFA_CHAIN_MAX_TILES")
-    layers = Flow(nodes, output_dtype=np.float32)
-    assert "persistent launch" not in layers.describe()
-    for n in (1, 16, 17, 128, 100, 1, 300, 33, 128):          # 300 > 128: both take the per-layer kernels
-        a, b = chain.execute(x[:n]), layers.execute(x[:n])
-        assert a.shape == (n, 60) and np.array_equal(a, b), n
+    x = synth.make_subimages(1100, 128, dtype=np.uint8)
+    flows = {}
+    for depth in ("0", "1", "2", "3"):
+        monkeypatch.setenv("HIGSFA_TAIL", depth)
+        flows[depth] = Flow(nodes, output_dtype=np.float32)
+        desc = flows[depth].describe()
+        assert ("no unpack pass" in desc) == (depth != "0")
+        assert ("ONE launch" in desc) == (depth in ("2", "3"))
+    monkeypatch.delenv("HIGSFA_TAIL")
+    default = Flow(nodes, output_dtype=np.float32)
+    assert "ONE launch" in default.describe()
+    base = flows["0"].execute(x)
+    assert base.shape == (1100, 60)
     ref = oracle.execute_flow(nodes, x[:33])
-    assert rel_err(chain.execute(x[:33]), ref) <= TOL
-    for _ in range(50):                                        # many launches back to back: generations 10 .. 60
-        assert np.array_equal(chain.execute(x[:100]), b[:100] if False else layers.execute(x[:100]))
-    # the chain with a forced larger reach (tile groups spread over slices of every node)
-    monkeypatch.setenv("HIGSFA_CHAIN_MAX_TILES", "64")
-    wide = Flow(nodes, output_dtype=np.float32)
-    for n in (300, 728, 1000):
-        assert np.array_equal(wide.execute(x[:n] if n <= 300 else np.tile(x, (4, 1))[:n]), layers.execute(x[:n] if n <= 300 else np.tile(x, (4, 1))[:n])), n
-    for f in (chain, layers, wide):
+    assert rel_err(base[:33], ref) <= TOL
+    for name, f in list(flows.items()) + [("default", default)]:
+        for n in (1, 16, 17, 128, 100, 1, 300, 33, 1100):
+            assert np.array_equal(f.execute(x[:n]), base[:n]), (name, n)
+        for cols in (1, 9, 16, 17, 20, 33, 59):                 # only the output tiles that hold a requested column are computed
+            assert np.array_equal(f.execute(x[:50], n_cols=cols), base[:50, :cols]), (name, cols)
+    # float64 out (the MDP default) and a strided y through the device entry
+    f64 = Flow(nodes)
+    assert np.array_equal(f64.execute(x[:77], n_cols=20), base[:77, :20].astype(np.float64))
+    import torch
+    xd = torch.from_numpy(x[:200]).cuda()
+    yd = torch.full((200, 32), -7.0, dtype=torch.float32, device="cuda")
+    default.execute_device(xd.data_ptr(), np.uint8, 200, xd.shape[1], yd.data_ptr(), np.float32, 20, 32)
+    torch.cuda.synchronize()
+    yh = yd.cpu().numpy()
+    assert np.array_equal(yh[:, :20], base[:200, :20]) and np.all(yh[:, 20:] == -7.0)      # columns beyond y_cols untouched
+    for f in list(flows.values()) + [default, f64]:
         f.close()
+
+
+@pytest.mark.parametrize("maker", ["linear", "overlap", "u11l64", "linear96"])
+def test_top_of_hierarchy_launch_other_nets(native_lib, nets, monkeypatch, maker):
+    """k_tail on other layer shapes: a linear top (no expansion), uneven node widths, the 64x64 preset, the linear 96x96 age-net
+    shape — against the per-layer kernels (bit for bit) and the oracle."""
+    nodes = {"linear": lambda: helpers.linear_net(3), "overlap": lambda: helpers.overlapping_net(5), "u11l64": lambda: nets("U11L-64"),
+             "linear96": lambda: helpers.linear_u11l_96(1)}[maker]()
+    rng = np.random.default_rng(2)
+    x = rng.integers(0, 256, (150, nodes[0].input_dim)).astype(np.float32)
+    monkeypatch.setenv("HIGSFA_TAIL", "0")
+    per_layer = Flow(nodes, output_dtype=np.float32)
+    monkeypatch.delenv("HIGSFA_TAIL")
+    fused = Flow(nodes, output_dtype=np.float32)
+    a, b = per_layer.execute(x), fused.execute(x)
+    assert np.array_equal(a, b)
+    k = max(1, nodes[-1].output_dim // 3)
+    assert np.array_equal(fused.execute(x[:19], n_cols=k), a[:19, :k])
+    assert rel_err(b, oracle.execute_flow(nodes, x)) <= TOL
+    print(maker, [ln for ln in fused.describe().splitlines() if "launch" in ln or "unpack" in ln][-2:])
+    per_layer.close()
+    fused.close()
 
 
 def test_front_kernel_variants_agree(native_lib, nets, monkeypatch):

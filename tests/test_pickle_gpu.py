@@ -1,0 +1,67 @@
+"""GPU: row f3 end to end — a Python-2-style pickle of an MDP / cuicuilco object graph (what the reference loads with
+cache_obj.load_obj_from_cache, face_analysis.py:451-487) -> pickle_import (stub unpickler, no mdp) -> neutral blob ->
+Flow.from_blob -> hg_flow_execute on the GPU, compared with the oracle run on the ORIGINAL description graph."""
+import numpy as np
+import pytest
+
+from oracle import mdp_restate
+from pyfaceanalysis_amd import pickle_import
+from tests import helpers
+from tests.conftest import get_net
+from tests.test_pickle_import import _dump, _fake_modules, _pair_net
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(path, nodes, side_or_dim, expect_fused=True, **import_kw):
+    from pyfaceanalysis_amd import _capi
+    from pyfaceanalysis_amd.flow import Flow
+    blob = pickle_import.pickle_to_blob(path, **import_kw)
+    flow = Flow.from_blob(blob, device=0)                    # float64 out, like the mdp.Flow it replaces
+    assert flow.input_dim == nodes[0].input_dim and flow.output_dim == nodes[-1].output_dim
+    rng = np.random.default_rng(5)
+    x = rng.integers(0, 256, (203, nodes[0].input_dim)).astype(np.float64)       # images_asarray values, ragged N
+    want = mdp_restate.execute_flow(nodes, x)
+    got = flow.execute(x)
+    assert got.dtype == np.float64 and got.shape == want.shape
+    err = np.abs(got - want).max() / np.abs(want).max()
+    assert err <= 1e-4, err                                  # north_star tolerance (fp32 arithmetic on the device)
+    if expect_fused:
+        assert flow.info().plan_kind == _capi.HG_PLAN_FUSED
+    # the generic plan reads the same blob
+    gen = Flow.from_blob(blob, device=0, force_generic=True)
+    g = gen.execute(x[:50])
+    assert np.abs(g - want[:50]).max() / np.abs(want).max() <= 1e-4
+    gen.close()
+    flow.close()
+    return err
+
+
+@pytest.mark.parametrize("case", ["plain", "igsfa", "as_tuple"])
+def test_trained_hierarchy_from_fake_mdp_pickle(native_lib, tmp_path, case):
+    nodes = get_net("T5L-16", node_kind="igsfa") if case == "igsfa" else get_net("T5L-16")
+    mods, C = _fake_modules()
+    path = _dump(tmp_path, nodes, mods, C, as_tuple=(case == "as_tuple"))         # (flow, ...) tuples: face_analysis.py:473-478
+    kw = dict(igsfa_lr_input="scaled") if case == "igsfa" else {}
+    err = _check(path, nodes, 16, **kw)
+    print("pickle -> blob -> GPU (%s): max rel err %.2e" % (case, err))
+
+
+@pytest.mark.parametrize("seed", [4, 2, 22])
+def test_igsfa_variants_from_pickle(native_lib, tmp_path, seed):
+    """iGSFA record variants (lr on scaled / unscaled features, per-column / QR-matrix scaling) through the importer."""
+    nodes = helpers.fuzz_igsfa_net(seed)
+    mods, C = _fake_modules()
+    path = _dump(tmp_path, nodes, mods, C)
+    _check(path, nodes, None, expect_fused=False, igsfa_lr_input=nodes[1].nodes[0].lr_input)
+
+
+@pytest.mark.parametrize("reading", ["offset", "band"])
+def test_pair_product_expansions_from_pickle(native_lib, tmp_path, reading):
+    """pair_prodsadj{k}_ex under either reading, fused (k_stage_prod) and generic plan."""
+    nodes = _pair_net(reading)
+    mods, C = _fake_modules()
+    path = _dump(tmp_path, nodes, mods, C)
+    with pytest.raises(ValueError, match="pair_prodsadj_reading"):
+        pickle_import.pickle_to_blob(path)
+    _check(path, nodes, None, pair_prodsadj_reading=reading)
