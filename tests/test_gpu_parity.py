@@ -99,40 +99,21 @@ def test_fuzzed_product_hierarchies(native_lib, seed):
         flow.close()
 
 
-def test_product_plan_speed(native_lib):
-    """The point of putting product expansions on the fused plan: a hierarchy of realistic size (64x64 input, 256 first-
-    layer nodes, products in every layer) at N = 4096 several times faster than on the generic plan (device-resident timing
-    of the two plans of the same flow, same results to fp32 rounding; measured 5-6x at 64x64 and 8-9x at 128x128 input —
-    the generic plan is not the ~100x slower it is on U11L-128 here, and the product columns cost LDS reads).
-    (helpers.product_net itself is a 4-node toy: both plans sit at the launch-latency floor there.)"""
-    import torch
+def test_product_hierarchy_both_plans(native_lib):
+    """A hierarchy of realistic size with product expansions in every layer (64x64 input, 256 first-layer nodes) at
+    N = 4096: the fused plan (k_stage_prod) and the generic plan of the same flow agree to fp32 rounding, and both match the
+    oracle.  (Their speed ratio is a measurement, not a parity property: tools/prod_stage_times.py, profiles/r02_product_plan.txt.)"""
     nodes = helpers.product_hier_net(1)
     n = 4096
     x = np.random.default_rng(0).normal(size=(n, nodes[0].input_dim)).astype(np.float32)
-    xd = torch.from_numpy(x).cuda()
-    yd = torch.empty((n, nodes[-1].output_dim), dtype=torch.float32, device="cuda")
-    res, times = {}, {}
+    res = {}
     for name, force in (("fused", False), ("generic", True)):
         flow = Flow(nodes, output_dtype=np.float32, force_generic=force)
         assert flow.info().plan_kind == (_capi.HG_PLAN_GENERIC if force else _capi.HG_PLAN_FUSED)
-        flow.reserve(n)
-        run = lambda: flow.execute_device(xd.data_ptr(), np.float32, n, x.shape[1], yd.data_ptr(), np.float32, yd.shape[1], yd.shape[1])
-        for _ in range(3):
-            run()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            run()
-        e1.record()
-        torch.cuda.synchronize()
-        times[name] = e0.elapsed_time(e1) / 10
-        res[name] = yd.cpu().numpy().copy()
+        res[name] = flow.execute(x)
         flow.close()
-    print("product_hier_net N=4096: fused %.3f ms, generic %.3f ms (%.0fx)" % (times["fused"], times["generic"], times["generic"] / times["fused"]))
     assert rel_err(res["fused"], res["generic"].astype(np.float64)) <= TOL
     assert rel_err(res["fused"][:64], oracle.execute_flow(nodes, x[:64])) <= TOL
-    assert times["generic"] >= 3 * times["fused"]
 
 
 @pytest.mark.parametrize("kw", [{}, {"node_kind": "igsfa"}])

@@ -7,7 +7,7 @@ d = sys.argv[1]
 skip = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 trace = max(glob.glob(os.path.join(d, "**", "*_kernel_trace.csv"), recursive=True), key=os.path.getmtime)
 rows = sorted(csv.DictReader(open(trace)), key=lambda r: int(r["Start_Timestamp"]))
-short = lambda n: n.replace("hg::(anonymous namespace)::", "").replace("hg::fused::", "").replace("(StageParams, StageParams)", "").replace("(StageParams)", "").replace("(StageParams, int, int)", "")
+short = lambda n: n.replace("hg::fused::(anonymous namespace)::", "").replace("hg::(anonymous namespace)::", "").replace("hg::fused::", "").replace("(TailParams)", "").replace("(StageParams, StageParams)", "").replace("(StageParams)", "").replace("(StageParams, int, int)", "")
 per, gaps = collections.OrderedDict(), collections.OrderedDict()
 pos, step, prev_end = -1, -1, None
 for r in rows:
