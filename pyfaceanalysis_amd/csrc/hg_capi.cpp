@@ -488,6 +488,33 @@ int hg_flow_execute_sharded(hg_flow* f, const void* x, int x_dtype, int64_t n, i
     });
 }
 
+int hg_event_create(void** ev) {
+    return guarded([&] {
+        if (!ev) hg::fail(HG_ERR_ARG, "null event pointer");
+        hipEvent_t e = nullptr;
+        HG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence));
+        *ev = (void*)e;
+    });
+}
+
+void hg_event_destroy(void* ev) {
+    if (ev) (void)hipEventDestroy((hipEvent_t)ev);
+}
+
+int hg_event_record(void* ev, void* stream) {
+    return guarded([&] {
+        if (!ev) hg::fail(HG_ERR_ARG, "null event");
+        HG_HIP(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream));
+    });
+}
+
+int hg_stream_wait_event(void* stream, void* ev) {
+    return guarded([&] {
+        if (!ev) hg::fail(HG_ERR_ARG, "null event");
+        HG_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)ev, 0));
+    });
+}
+
 int hg_flow_set_profiling(hg_flow* f, int enabled) {
     return guarded([&] {
         if (!f) hg::fail(HG_ERR_ARG, "null flow handle");

@@ -687,18 +687,21 @@ __global__ void __launch_bounds__(256) k_stage_splitm(StageParams P, int mt1n, i
 #pragma unroll
         for (int t = 0; t < T; ++t) z[t] = bb;
         for (int k0 = 0; k0 < P.kb1; k0 += KB) {
+            // the whole batch of K-block entries first (scalar loads that do not wait for one another; the table has 8 spare
+            // entries behind the last node), then every weight / input block of the batch, then the MFMAs
+            int2 ent[KB];
+#pragma unroll
+            for (int k = 0; k < KB; ++k) ent[k] = kt[k0 + k];
             f32x4 a1[KB], bf[KB][T];
             int nks[KB];
 #pragma unroll
             for (int k = 0; k < KB; ++k) {
-                nks[k] = 0;
-                if (k0 + k < P.kb1) {
-                    const int2 e = kt[k0 + k];
-                    nks[k] = e.y;
-                    a1[k] = wnode[((size_t)(k0 + k) * mt1n + w) * 64];
+                const bool real = k0 + k < P.kb1;
+                nks[k] = real ? ent[k].y : 0;
+                const int sb = real ? ent[k].x : ent[0].x, wk = real ? k0 + k : k0;      // (blocks beyond the node's: a harmless re-read, no MFMA)
+                a1[k] = wnode[((size_t)wk * mt1n + w) * 64];
 #pragma unroll
-                    for (int t = 0; t < T; ++t) bf[k][t] = P.in[(size_t)(trow[t] + e.x) * 64 + lane];
-                }
+                for (int t = 0; t < T; ++t) bf[k][t] = P.in[(size_t)(trow[t] + sb) * 64 + lane];
             }
             if (REM && rem1) {
 #pragma unroll
@@ -715,12 +718,19 @@ __global__ void __launch_bounds__(256) k_stage_splitm(StageParams P, int mt1n, i
 #pragma unroll
                 for (int k = 0; k < KB; ++k) {
                     const int nk = nks[k] & 255, r0 = nks[k] >> 8;      // (r0 > 0: a packed remainder block)
+                    if (nks[k] == 4) {      // a whole block: four k-steps, no branch between them
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (r >= r0 && r < nk) {
+                        for (int r = 0; r < 4; ++r)
 #pragma unroll
                             for (int t = 0; t < T; ++t) z[t] = MFMA16(a1[k][r], bf[k][t][r], z[t]);
-                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (r >= r0 && r < nk) {
+#pragma unroll
+                                for (int t = 0; t < T; ++t) z[t] = MFMA16(a1[k][r], bf[k][t][r], z[t]);
+                            }
+                    }
                 }
             }
         }
@@ -768,6 +778,11 @@ __global__ void __launch_bounds__(256) k_stage_splitm(StageParams P, int mt1n, i
 #pragma unroll
                     for (int t = 0; t < T; ++t) d4[t] = MFMA4(a2[k][r], e[t][r], d4[t]);
                 }
+        } else if (nk == 4) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int t = 0; t < T; ++t) y[t] = MFMA16(a2[k][r], e[t][r], y[t]);
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -1191,6 +1206,8 @@ public:
             col_base_[c] = prev_blk[c] * 256 + (q & 3) * 64 + (q >> 2);
             col_of_[(size_t)prev_blk[c] * 16 + q] = c;
         }
+        for (auto& hs : stages_)      // k_tail reads 8 K-block entries at once from a node's first: 8 spare ones behind the last node's
+            if (!hs.kb1tab.empty()) hs.kb1tab.resize(hs.kb1tab.size() + 16, 0);
         plan_tail();
     }
 

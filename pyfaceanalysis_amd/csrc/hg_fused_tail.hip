@@ -91,31 +91,41 @@ __device__ __forceinline__ void tail_layer(const TailParams& P, const TailStage&
 #pragma unroll
         for (int t = 0; t < T; ++t) z[t] = bb;
         for (int k0 = 0; k0 < S.kb1; k0 += KB) {
+            // the whole batch of K-block entries first (scalar loads that do not wait for one another; the table has 8 spare
+            // entries behind the last node), then every weight / input block of the batch, then the MFMAs
+            int2 ent[KB];
+#pragma unroll
+            for (int k = 0; k < KB; ++k) ent[k] = kt[k0 + k];
             f32x4 a1[KB], bf[KB][T];
             int nks[KB];
 #pragma unroll
             for (int k = 0; k < KB; ++k) {
-                nks[k] = 0;
-                if (k0 + k < S.kb1) {
-                    const int2 e = kt[k0 + k];
-                    nks[k] = e.y;
-                    a1[k] = wnode[((size_t)(k0 + k) * mt1n + mw) * 64];
+                const bool real = k0 + k < S.kb1;
+                nks[k] = real ? ent[k].y : 0;
+                const int sb = real ? ent[k].x : ent[0].x, wk = real ? k0 + k : k0;      // (blocks beyond the node's: a harmless re-read, no MFMA)
+                a1[k] = wnode[((size_t)wk * mt1n + mw) * 64];
 #pragma unroll
-                    for (int t = 0; t < T; ++t) {
-                        if constexpr (FIRST) bf[k][t] = P.in[(size_t)(trow[t] + e.x) * 64 + lane];
-                        else bf[k][t] = src[((size_t)e.x * T + t) * 64 + lane];
-                    }
+                for (int t = 0; t < T; ++t) {
+                    if constexpr (FIRST) bf[k][t] = P.in[(size_t)(trow[t] + sb) * 64 + lane];
+                    else bf[k][t] = src[((size_t)sb * T + t) * 64 + lane];
                 }
             }
 #pragma unroll
             for (int k = 0; k < KB; ++k) {
                 const int nk = nks[k] & 255, r0 = nks[k] >> 8;      // (r0 > 0: a packed remainder block of the layer below)
+                if (nks[k] == 4) {      // a whole block: four k-steps, no branch between them
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (r >= r0 && r < nk) {
+                    for (int r = 0; r < 4; ++r)
 #pragma unroll
                         for (int t = 0; t < T; ++t) z[t] = MFMA16(a1[k][r], bf[k][t][r], z[t]);
-                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (r >= r0 && r < nk) {
+#pragma unroll
+                            for (int t = 0; t < T; ++t) z[t] = MFMA16(a1[k][r], bf[k][t][r], z[t]);
+                        }
+                }
             }
         }
         if (!S.has_exp) {
@@ -143,12 +153,19 @@ __device__ __forceinline__ void tail_layer(const TailParams& P, const TailStage&
             f32x4 e[T];
 #pragma unroll
             for (int t = 0; t < T; ++t) e[t] = ebuf[((((size_t)node * nf + fi) * mt1n + mt1) * T + t) * 64 + lane];
+            if (nk == 4) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (r < nk) {
+                for (int r = 0; r < 4; ++r)
 #pragma unroll
                     for (int t = 0; t < T; ++t) y[t] = MFMA16(a2[k][r], e[t][r], y[t]);
-                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (r < nk) {
+#pragma unroll
+                        for (int t = 0; t < T; ++t) y[t] = MFMA16(a2[k][r], e[t][r], y[t]);
+                    }
+            }
         }
         emit(y);
     }

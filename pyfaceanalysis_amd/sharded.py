@@ -47,7 +47,8 @@ class ShardedFlow(object):
     ``collective``: issue the all-gather (default: whenever a process group is initialised).
 
     On a GPU the gather of step i runs on a side stream under the kernels of step i+1 (two feature
-    buffers, events in both directions); ``step`` returns the tensor the gather writes, valid once
+    buffers, events in both directions — device-scope events of the library, ``hg_event_*``: a default event's
+    record writes the caches back to system scope and held the next launch up by 13 us); ``step`` returns the tensor the gather writes, valid once
     ``wait()`` has returned or ``done_event(i)`` of that step has been waited for, and ONLY until step
     i + 2 is enqueued, which writes the same buffer again: a consumer that needs it longer copies it.
     """
@@ -74,7 +75,19 @@ class ShardedFlow(object):
         if self.cuda:
             self.stream = torch.cuda.current_stream(self.device)
             self.comm = torch.cuda.Stream(self.device) if self.collective else None
-            self.gathered = [torch.cuda.Event(), torch.cuda.Event()]
+            self.gathered = [torch.cuda.Event(), torch.cuda.Event()]     # for the caller (done_event): recorded on the side stream
+            self._light = None
+            if self.collective:
+                # device-scope events ordering the two streams against each other: [0/1] "gather of buffer b enqueued so far is
+                # done" (side stream -> kernels), [2] "kernels of this step are done" (kernels -> side stream)
+                import ctypes as C
+                from . import _capi
+                self._capi, self._light = _capi, []
+                for _ in range(3):
+                    h = C.c_void_p()
+                    _capi.check(_capi.lib().hg_event_create(C.byref(h)))
+                    self._light.append(h)
+                self._recorded = [False, False]
 
     @classmethod
     def for_flow(cls, flow, n_cols, rows, device, collective=None):
@@ -100,8 +113,9 @@ class ShardedFlow(object):
         m = int(x_local.shape[0])
         if m > self.rows:
             raise ValueError("rank %d: local block has %d rows, more than the %d allocated" % (self.rank, m, self.rows))
-        if self.cuda and self.collective:
-            self.stream.wait_event(self.gathered[b])      # the gather that read ys[b] two steps ago is done
+        if self.cuda and self.collective and self._recorded[b]:
+            # the gather that read ys[b] two steps ago is done
+            self._capi.check(self._capi.lib().hg_stream_wait_event(self.stream.cuda_stream, self._light[b]))
         if m < self._filled[b]:         # a fuller step used this buffer before: its rows m.. must not be published again
             if self.cuda:
                 with torch.cuda.stream(self.stream):
@@ -114,11 +128,13 @@ class ShardedFlow(object):
         if not self.collective:
             return self.ys[b]
         if self.cuda:
-            done = torch.cuda.Event()
-            done.record(self.stream)
-            self.comm.wait_event(done)
+            L = self._capi.lib()
+            self._capi.check(L.hg_event_record(self._light[2], self.stream.cuda_stream))
+            self._capi.check(L.hg_stream_wait_event(self.comm.cuda_stream, self._light[2]))
             with torch.cuda.stream(self.comm):
                 gather_features(self.ys[b], self.y_alls[b])
+                self._capi.check(L.hg_event_record(self._light[b], self.comm.cuda_stream))
+                self._recorded[b] = True
                 self.gathered[b].record(self.comm)
         else:
             gather_features(self.ys[b], self.y_alls[b])
@@ -133,6 +149,19 @@ class ShardedFlow(object):
         if not (last - 1 <= i <= last) or i < 0:
             raise ValueError("step %d: only the two most recent steps (%d, %d) still own a buffer" % (i, last - 1, last))
         return self.gathered[i & 1] if (self.cuda and self.collective) else None
+
+    def close(self):
+        if getattr(self, "_light", None):
+            self.wait()
+            for h in self._light:
+                self._capi.lib().hg_event_destroy(h)
+            self._light = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def wait(self):
         """Block until everything enqueued so far (kernels and gathers) is complete."""

@@ -46,7 +46,7 @@ FLOW_ROLE = {"Disc1": 0, "Disc3": 0, "Disc5": 0, "Disc7": 0, "Disc9": 1, "PosX0"
 N_CLASSES = {"Disc": 10, "PosX": 50, "PosY": 50, "PAng": 50, "Scale": 50}
 
 
-def build_face_cascade(flow, features, pipeline=None, keep_fraction=0.1, n_classes=None, device=0, stages=None):
+def build_face_cascade(flow, features, pipeline=None, keep_fraction=0.1, n_classes=None, device=0, stages=None, later_keep_fraction=None):
     """Stages of the synthetic face cascade.
 
     ``flow``: ONE Flow that every network-owning stage runs, or a list of four (the reference's pipeline uses four trained
@@ -54,15 +54,19 @@ def build_face_cascade(flow, features, pipeline=None, keep_fraction=0.1, n_class
     per flow — used to calibrate the classifiers so that the first Disc stage keeps about ``keep_fraction`` of the windows
     and the pose stages propose small corrections inside their training ranges (Pipeline header: Dx 40, Dy 20, Dang 22.5,
     scale 0.694..0.981).  ``n_classes``: classes of every classifier (default: the reference's files' — 10 for Disc, 50 for
-    the pose regressors).  ``stages``: another (name, owns a network, classifier width) list than ``FACE_STAGES``."""
+    the pose regressors).  ``stages``: another (name, owns a network, classifier width) list than ``FACE_STAGES``.
+    ``later_keep_fraction``: share of classes labelled "face" in the Disc stages after the first (default: keep_fraction) —
+    with four unrelated synthetic networks a window that passed one Disc stage is a random window for the next one's network,
+    so the later stages need a laxer labelling to thin the candidates out gradually (340 -> 135 -> 55 -> 27 -> a few on the
+    1080p frame) the way one shared network did."""
     p = dict(grid.FACE_PIPELINE if pipeline is None else pipeline)
     flows = list(flow) if isinstance(flow, (list, tuple)) else [flow] * 4
     feats = list(features) if isinstance(features, (list, tuple)) else [features] * 4
     if len(flows) != 4 or len(feats) != 4:
         raise ValueError("build_face_cascade: one flow or four (FLOW_ROLE), with one feature sample each")
 
-    def labels(kind, k):
-        n_face = max(1, int(round(k * keep_fraction)))
+    def labels(kind, k, first=True):
+        n_face = max(1, int(round(k * (keep_fraction if first or later_keep_fraction is None else later_keep_fraction))))
         return {
             "Disc": np.array([0.0] * n_face + [1.0] * (k - n_face)),
             # small corrections: the synthetic networks carry no face semantics, so a window that moved far would get unrelated
@@ -74,6 +78,7 @@ def build_face_cascade(flow, features, pipeline=None, keep_fraction=0.1, n_class
         }[kind]
     out = []
     role = 0
+    seen_disc = False
     for name, own, d in (FACE_STAGES if stages is None else stages):
         if own:
             role = FLOW_ROLE.get(name, 0)          # a stage without a network reads the features of the last flow that ran
@@ -81,5 +86,6 @@ def build_face_cascade(flow, features, pipeline=None, keep_fraction=0.1, n_class
         d = min(d, f.shape[1])                     # small test networks have fewer than 20 outputs
         k = N_CLASSES[name[:-1]] if n_classes is None else n_classes
         k = max(2, min(k, len(f) // 4))            # tiny calibration samples: fewer classes than rows
-        out.append(Stage(name, flows[role] if own else None, quantile_classifier(f, d, labels(name[:-1], k), device=device)))
+        out.append(Stage(name, flows[role] if own else None, quantile_classifier(f, d, labels(name[:-1], k, first=not seen_disc), device=device)))
+        seen_disc = seen_disc or name[:-1] == "Disc"
     return out

@@ -202,7 +202,7 @@ def test_u11l64_layer_by_layer_equivalence_and_invariants(native_lib, nets):
             assert np.all(np.diff(d) > -1e-9 * d.max())
         cur = y_np
     print("teacher-forced layer outputs, GPU vs numpy trainer, max relative difference per layer:", " ".join("%.1e" % w for w in worst_forced))
-    assert max(worst_forced) <= 1e-6, worst_forced
+    assert max(worst_forced) <= 1e-9, worst_forced          # measured: 2e-12 ... 5e-11 at every layer
     # no growth with depth: the top layers are not worse than the worst of the bottom five by more than 100x
     assert max(worst_forced[5:]) <= 100 * max(max(worst_forced[:5]), 1e-12), worst_forced
     # ---- (2) + (3) end to end
@@ -234,5 +234,6 @@ def test_u11l64_layer_by_layer_equivalence_and_invariants(native_lib, nets):
     print("end to end, held-out sequence: output drift per layer", " ".join("%.1e" % w for w in drift))
     print("                               relative difference of the first 20 delta values per layer", " ".join("%.1e" % w for w in rel_delta))
     print("                               smallest cosine between the first-20-feature subspaces at the top: 1 - %.2e" % (1 - cosines.min()))
-    assert max(rel_delta) <= 1e-2 and rel_delta[0] <= 1e-8
-    assert cosines.min() >= 1 - 1e-4
+    # measured: delta values 3e-12 (layer 0) ... 4.5e-4 (layer 10) while the raw outputs drift 1e-11 ... 1.7e-3; 1 - cos = 4e-7
+    assert max(rel_delta) <= 5e-3 and rel_delta[0] <= 1e-10 and max(rel_delta[:6]) <= 1e-6
+    assert cosines.min() >= 1 - 1e-5
