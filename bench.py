@@ -153,7 +153,7 @@ def _frame_leg(flow, dev, reps, flow_factory):
         return out_
     flows4 = four_flows(flow)
     feats4 = calib(flows4)
-    stages = synth_cascade.build_face_cascade(flows4, feats4, pipe, keep_fraction=0.1, later_keep_fraction=0.4)
+    stages = synth_cascade.build_face_cascade(flows4, feats4, pipe, keep_fraction=0.2, later_keep_fraction=0.6)
     dc = DeviceCascade(stages, (SIDE, SIDE), N_COLS, pipe)
     win = (boxes, level)
     for _ in range(3):
@@ -181,7 +181,7 @@ def _frame_leg(flow, dev, reps, flow_factory):
         extra = []
         for _ in range(3):
             f2 = four_flows(flow_factory())
-            extra.append((f2, DeviceCascade(synth_cascade.build_face_cascade(f2, feats4, pipe, keep_fraction=0.1, later_keep_fraction=0.4), (SIDE, SIDE), N_COLS, pipe)))
+            extra.append((f2, DeviceCascade(synth_cascade.build_face_cascade(f2, feats4, pipe, keep_fraction=0.2, later_keep_fraction=0.6), (SIDE, SIDE), N_COLS, pipe)))
         cascades = [dc] + [c for _, c in extra]
         streams = [torch.cuda.Stream(dev) for _ in cascades]
         outs = [None] * len(cascades)

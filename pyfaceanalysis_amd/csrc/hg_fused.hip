@@ -1311,9 +1311,9 @@ public:
                 }
                 return R;
             };
-            if (tail_begin_ >= 0 && (int)si == tail_begin_) {
+            if (tail_begin_ >= 0 && (int)si == tail_start(n_tiles)) {
                 // the top of the hierarchy as one launch that ends in the caller's rows (hg_fused_tail.hip)
-                TailParams TP = tail_params(cur, n_tiles, y, y_dtype, y_cols, ldy, n);
+                TailParams TP = tail_params((int)si, cur, n_tiles, y, y_dtype, y_cols, ldy, n);
                 const int T = (n_tiles >= 512 && tail_waves(TP) <= 8) ? 2 : 1;
                 launch_tail(TP, T, st);
                 if (ev)
@@ -2383,12 +2383,20 @@ private:
                                       : "  [in the top-of-hierarchy launch]";
     }
 
-    TailParams tail_params(const f32x4* in, int n_tiles, void* y, int y_dtype, int64_t y_cols, int64_t ldy, int64_t n) {
+    // Three fused layers pay off from ~1400 rows on (call times against N, profiles/r03_call_times.txt: 16 waves per workgroup walk
+    // the three layers' latencies one after the other — 23 us however small the batch, against 6 us for a k_stage_splitm launch of
+    // the 4-node layer plus 13 us for the two layers above it); below that the launch starts one layer later.  Same bits either way.
+    int tail_start(int n_tiles) const {
+        const int ns = (int)stages_.size();
+        return (ns - tail_begin_ >= 3 && n_tiles < 96) ? tail_begin_ + 1 : tail_begin_;
+    }
+
+    TailParams tail_params(int begin, const f32x4* in, int n_tiles, void* y, int y_dtype, int64_t y_cols, int64_t ldy, int64_t n) {
         TailParams TP{};
         const int ns = (int)stages_.size();
-        TP.n_stages = ns - tail_begin_;
+        TP.n_stages = ns - begin;
         for (int k = 0; k < TP.n_stages; ++k) {
-            HostStage& hs = stages_[tail_begin_ + k];
+            HostStage& hs = stages_[begin + k];
             TailStage& S = TP.st[k];
             S.afrag = (const f32x4*)hs.d_afrag.p;
             S.bias = (const float*)hs.d_bias.p;
@@ -2418,7 +2426,7 @@ private:
         TP.y_f64 = y_dtype == HG_F64 ? 1 : 0;
         if (y_dtype != HG_F32 && y_dtype != HG_F64) fail(HG_ERR_ARG, "output dtype must be f32 or f64");
         TP.n_tiles = n_tiles;
-        TP.nb_in = stages_[tail_begin_].nb_in;
+        TP.nb_in = stages_[begin].nb_in;
         TP.act_blocks = tail_act_blocks_;
         TP.e_blocks = tail_e_blocks_;
         return TP;

@@ -99,7 +99,7 @@ def test_device_cascade_matches_restated_loop(native_lib, nets, sequence):
     pt = Patcher()
     subs0 = pt.extract(frame, boxes, (16, 16), dtype=np.uint8)
     feats = flow.execute(subs0)
-    stages = synth_cascade.build_face_cascade(flows, [f.execute(subs0) for f in flows], pipe, keep_fraction=0.4, stages=AWKWARD[sequence])
+    stages = synth_cascade.build_face_cascade(flows, [f.execute(subs0) for f in flows], pipe, keep_fraction=0.7, stages=AWKWARD[sequence])
     assert len({id(s.flow) for s in stages if s.flow is not None}) >= 3
     dc = DeviceCascade(stages, (16, 16), K, pipe)
     got = dc.detect(torch.from_numpy(frame).cuda(), smallest_face=0.3)

@@ -94,3 +94,16 @@ def test_world_size_2_gloo(tmp_path):
     for rank in range(2):
         f = tmp_path / ("rank%d.ok" % rank)
         assert f.exists() and f.read_text().strip() == "4", out[-3000:]
+
+
+def test_bench_starts_its_own_ranks_or_says_why_not():
+    """`python bench.py --gpus N` (N > 1) without a launcher is a parent that never touches HIP: it checks the visible
+    devices and starts torch.distributed.run as a child.  This container has no GPU, so the parent must stop with exit code 2
+    and a message — not fall into the single-rank path, not hang, not raise."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("a multi-GPU box would really start the ranks")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=dict(os.environ, OMP_NUM_THREADS="2"))
+    assert r.returncode == 2, (r.returncode, r.stderr.decode(errors="replace")[-2000:])
+    assert b"--gpus 2 asked for" in r.stderr and not r.stdout.strip()
