@@ -125,3 +125,47 @@ def test_collective_step_costs_no_more_than_collective_free(rccl_world1):
     base = min(res["collective_free"], res["collective_free_again"])
     assert res["rccl_world1"] <= base * 1.10 + 0.02, res
     flow.close()
+
+
+def test_config4_global_batch_on_one_gpu(native_lib):
+    """BASELINE.json configs[3] at its full GLOBAL size — 32768 sub-images of 128x128, cut into the eight row blocks
+    `shard_bounds` gives the ranks — on the one GPU a test box has: every block through ShardedFlow's per-rank path
+    (collective-free here) lands in the gathered matrix where the sharding says, and that matrix equals, bit for bit, ONE
+    device-resident execute over all 32768 rows (rows are independent: FaceDetectUpdated.py:739-759; results do not depend
+    on the batch a row travels in).  A sample of rows against the oracle; a row permutation permutes the features."""
+    import torch
+    from oracle import mdp_restate
+    from pyfaceanalysis_amd import synth
+    from pyfaceanalysis_amd.sharded import ShardedFlow, shard_bounds
+    flow, nodes = _flow("U11L-128")
+    dev = torch.device("cuda", 0)
+    n_total, world = 32768, 8
+    base = synth.make_subimages(4096, 128, dtype=np.uint8)
+    x_host = np.concatenate([np.roll(base, 131 * r + 7, axis=1) for r in range(world)])          # eight distinct blocks
+    assert x_host.shape == (n_total, 16384)
+    x = torch.from_numpy(x_host).to(dev)
+    # one call over the whole global batch
+    y_one = torch.empty((n_total, K), dtype=torch.float32, device=dev)
+    flow.execute_device(x.data_ptr(), np.uint8, n_total, x.shape[1], y_one.data_ptr(), np.float32, K, K)
+    torch.cuda.synchronize()
+    # the eight ranks' blocks, one after the other, into the gathered layout
+    gathered = torch.zeros((n_total, K), dtype=torch.float32, device=dev)
+    for r in range(world):
+        lo, hi, per = shard_bounds(n_total, world, r)
+        assert (lo, hi, per) == (4096 * r, 4096 * (r + 1), 4096)
+        sf = ShardedFlow.for_flow(flow, K, per, dev, collective=False)
+        gathered[r * per:(r + 1) * per] = sf.execute(x[lo:hi])
+    assert torch.equal(gathered, y_one)
+    got = y_one.cpu().numpy()
+    idx = np.arange(5, n_total, 1171)
+    ref = mdp_restate.execute_flow(nodes, x_host[idx])[:, :K]
+    assert np.abs(got[idx] - ref).max() <= 1e-4 * np.abs(ref).max()
+    assert len(np.unique(got[::4096].round(4), axis=0)) == world            # the blocks really differ
+    # permutation of the rows of one block permutes its features
+    perm = torch.randperm(4096, device=dev)
+    y_p = torch.empty((4096, K), dtype=torch.float32, device=dev)
+    xp = x[4096:8192][perm].contiguous()
+    flow.execute_device(xp.data_ptr(), np.uint8, 4096, xp.shape[1], y_p.data_ptr(), np.float32, K, K)
+    torch.cuda.synchronize()
+    assert torch.equal(y_p, y_one[4096:8192][perm])
+    flow.close()
