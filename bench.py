@@ -333,6 +333,43 @@ def train_leg(dev, n=100_000):
             "max_rel_err_eigenvalues_vs_scipy": worst_val, "max_err_eigenvectors_vs_scipy": worst_vec, "nodes_checked": 3, "budget": 1e-5}
 
 
+def bf16x3_leg(blob, nodes, dev, rows, steps):
+    """EXPERIMENT, not the headline and not its arithmetic: the same step with HIGSFA_BF16X3=1 — layers 3..7 with every fp32
+    product replaced by six bf16 products on v_mfma_f32_16x16x32_bf16 (fp32 accumulate; hg_fused_b3.hip).
+    Reported with its own error against the oracle so that the trade can be judged; `dtype` of the bench line stays f32 and
+    describes the default plan only."""
+    import torch
+    from oracle import mdp_restate
+    from pyfaceanalysis_amd import synth
+    from pyfaceanalysis_amd.flow import Flow
+    os.environ["HIGSFA_BF16X3"] = "1"          # read once, when the plan is built
+    try:
+        flow = Flow.from_blob(blob, device=dev.index, output_dtype=np.float32)
+        flow.reserve(rows)
+    finally:
+        os.environ.pop("HIGSFA_BF16X3", None)
+    n_exp = sum("HIGSFA_BF16X3" in ln for ln in flow.describe().splitlines())
+    xh = synth.make_subimages(rows, SIDE, dtype=np.float32)
+    x = torch.from_numpy(xh).to(dev)
+    y = torch.empty((rows, N_COLS), dtype=torch.float32, device=dev)
+    st = torch.cuda.current_stream(dev)
+
+    def run(k):
+        for _ in range(k):
+            flow.execute_device(x.data_ptr(), np.float32, rows, x.shape[1], y.data_ptr(), np.float32, N_COLS, N_COLS, stream=st.cuda_stream)
+        torch.cuda.synchronize(dev)
+    run(max(100, steps // 4))
+    t0 = time.perf_counter()
+    run(steps)
+    dt = (time.perf_counter() - t0) / steps
+    ref = mdp_restate.execute_flow(nodes, xh[:64].astype(np.float64))[:, :N_COLS]
+    err = float(np.abs(y[:64].cpu().numpy() - ref).max() / np.abs(ref).max())
+    flow.close()
+    return {"arithmetic": "layers 3-7: six bf16 products per fp32 product (operands split h + m + l on the fly / on the host), fp32 accumulate; "
+                          "all other layers exact fp32 as in the headline", "layers_on_split_bf16": n_exp, "sub_images_per_s": rows / dt,
+            "ms_per_step": dt * 1e3, "max_rel_err_vs_oracle": err, "note": "labelled side experiment (HIGSFA_BF16X3=1); never the default plan"}
+
+
 def uniform_leg(flow, nodes, dev, rows, steps):
     """SURVEY.md §8d's stress variant of the input: pure uniform random pixels (no 3x3 low-pass), same step, same checks."""
     import torch
@@ -680,6 +717,7 @@ def main():
             out["u11l_64"] = u11l_64_leg(dev, rows, leg_steps)
             out["host_path"] = host_path_leg(blob)
             out["train_leg"] = train_leg(dev)
+            out["bf16x3_experiment"] = bf16x3_leg(blob, nodes, dev, rows, leg_steps)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(nodes)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
