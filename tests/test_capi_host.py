@@ -236,3 +236,11 @@ def test_no_gpu_means_loud_failure(native_lib, nets):
     g = GaussianClassifier(np.zeros((2, 3)), np.stack([np.eye(3)] * 2), np.ones(2), np.ones(2) / 2, avg_labels=[0.0, 1.0])
     with pytest.raises(RuntimeError, match="no HIP device"):
         g.regression(np.zeros((2, 3)))
+
+
+def test_ordering_event_entry_points_reject_null(native_lib):
+    """hg_event_* (device-scope ordering events for pyfaceanalysis_amd/sharded.py): argument checks work without a GPU."""
+    assert native_lib.hg_event_create(None) == _capi.HG_ERR_ARG
+    assert native_lib.hg_event_record(None, None) == _capi.HG_ERR_ARG and b"null event" in native_lib.hg_last_error()
+    assert native_lib.hg_stream_wait_event(None, None) == _capi.HG_ERR_ARG
+    native_lib.hg_event_destroy(None)          # a no-op
