@@ -131,6 +131,9 @@ int hg_event_create(void** ev);
 void hg_event_destroy(void* ev);
 int hg_event_record(void* ev, void* stream);
 int hg_stream_wait_event(void* stream, void* ev);
+/* 1 when everything the event was last recorded behind has completed, 0 when not yet (never blocks); < 0: hg_status.
+ * Lets the host skip a wait that would only put a barrier packet in front of the next launch (measured: 4.5 us). */
+int hg_event_query(void* ev);
 
 /* Per-stage timing (the `benchmark=` kwarg of the reference call; benchmarking.py:39-58).
  * When enabled every stage launch is bracketed by hipEvents on the execution stream. */

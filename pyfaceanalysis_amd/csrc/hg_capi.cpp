@@ -515,6 +515,18 @@ int hg_stream_wait_event(void* stream, void* ev) {
     });
 }
 
+int hg_event_query(void* ev) {
+    int done = 0;
+    const int rc = guarded([&] {
+        if (!ev) hg::fail(HG_ERR_ARG, "null event");
+        const hipError_t e = hipEventQuery((hipEvent_t)ev);
+        if (e == hipSuccess) done = 1;
+        else if (e == hipErrorNotReady) (void)hipGetLastError();      // not an error: clear the sticky code
+        else HG_HIP(e);
+    });
+    return rc == HG_OK ? done : rc;
+}
+
 int hg_flow_set_profiling(hg_flow* f, int enabled) {
     return guarded([&] {
         if (!f) hg::fail(HG_ERR_ARG, "null flow handle");

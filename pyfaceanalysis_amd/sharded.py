@@ -114,8 +114,15 @@ class ShardedFlow(object):
         if m > self.rows:
             raise ValueError("rank %d: local block has %d rows, more than the %d allocated" % (self.rank, m, self.rows))
         if self.cuda and self.collective and self._recorded[b]:
-            # the gather that read ys[b] two steps ago is done
-            self._capi.check(self._capi.lib().hg_stream_wait_event(self.stream.cuda_stream, self._light[b]))
+            # The gather that read ys[b] two steps ago must be done before the kernels write ys[b] again.  It almost always
+            # is, long ago: ask first (non-blocking) and spare the kernels' queue a barrier packet in front of its next
+            # launch (4.5 us, tools/ubench/event_gap.hip); only a gather still in flight gets the device-side wait.
+            L = self._capi.lib()
+            q = L.hg_event_query(self._light[b])
+            if q < 0:
+                self._capi.check(q)
+            if q == 0:
+                self._capi.check(L.hg_stream_wait_event(self.stream.cuda_stream, self._light[b]))
         if m < self._filled[b]:         # a fuller step used this buffer before: its rows m.. must not be published again
             if self.cuda:
                 with torch.cuda.stream(self.stream):

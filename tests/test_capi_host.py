@@ -243,4 +243,5 @@ def test_ordering_event_entry_points_reject_null(native_lib):
     assert native_lib.hg_event_create(None) == _capi.HG_ERR_ARG
     assert native_lib.hg_event_record(None, None) == _capi.HG_ERR_ARG and b"null event" in native_lib.hg_last_error()
     assert native_lib.hg_stream_wait_event(None, None) == _capi.HG_ERR_ARG
+    assert native_lib.hg_event_query(None) == _capi.HG_ERR_ARG
     native_lib.hg_event_destroy(None)          # a no-op
