@@ -461,8 +461,10 @@ int hg_cascade_detect_device(hg_cascade* c, const void* frame_dev, int frame_h, 
             A.k_feat = c->k;
             A.cur = cur;
             A.n_max = (int32_t)n_bound;
-            // the host needs the exact count only where it shrinks a lot and sizes expensive launches: after a Disc stage
-            const bool want_count = S.type == HG_STAGE_DISC || k + 1 == ns;
+            // the host needs the exact count only where it shrinks a lot and sizes expensive launches: after a Disc stage — and only
+            // while there is something to save: a flow call on <= 128 rows sits at its latency floor (63-88 us),
+            // less than what the read-back and the host's catching up with the device cost (~30-50 us)
+            const bool want_count = (S.type == HG_STAGE_DISC && n_bound > 128) || k + 1 == ns;
             hipLaunchKernelGGL(k_cascade_stage, 1, 1024, 0, st, S.type, cc, A, want_count ? c->host_count : nullptr);
             if (carry[(size_t)k]) {       // this stage's compaction applied to the sub-images as well (:753)
                 const int vec16 = row % 16 == 0 ? 1 : 0;

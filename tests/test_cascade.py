@@ -123,8 +123,9 @@ def test_device_cascade_matches_restated_loop(native_lib, nets, sequence):
     ref = CR.run_cascade([s.name for s in stages], [s.flow is not None for s in stages], boxes, level, pipe, extract, execute, regress)
     assert [k for k, _ in checked] == list(range(len(stages))) and all(n > 0 for _, n in checked)     # every stage, on real rows
     # survivor counts are read back after Disc stages only (-1 elsewhere: the count stays on the device)
+    # (and only while more than 128 candidates are left: below that the read-back costs more than it saves)
     known = [i for i, c in enumerate(got["counts"]) if c >= 0 and stages[i].type == "Disc"]
-    assert len(known) == sum(s.type == "Disc" for s in stages)
+    assert 1 <= len(known) <= sum(s.type == "Disc" for s in stages) and known[0] == 0
     assert [got["counts"][i] for i in known] == [ref["counts"][i] for i in known], (got["counts"], ref["counts"])
     assert got["rows_executed"] >= ref["rows_executed"]        # launches between two Disc stages are sized by the last count read
     assert 0 < got["counts"][-1] < len(boxes) and got["counts"][0] < len(boxes)
