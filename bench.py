@@ -232,27 +232,42 @@ def _frame_leg(flow, dev, reps, flow_factory):
 
 def host_path_leg(blob):
     """The reference's actual call hands over HOST ndarrays (face_analysis.py:786 -> FaceDetectUpdated.py:699): time
-    hg_flow_execute — pack / narrow, H2D, all kernels, D2H, synchronous — on float64 (what images_asarray yields) and
-    uint8 batches of 4096 and 728 rows (728 = the largest single execute of a real 1080p frame).  Best of 5
-    after two warm-up calls.  `caller_GBps` = bytes of the caller's array per second (float64 rows holding integer pixel
-    values cross PCIe as uint8 after the exact narrowing, so this is NOT the PCIe rate)."""
+    hg_flow_execute — packers narrowing / copying rows straight into device memory, passes sized by the planner, features
+    back, synchronous — on float64 (what images_asarray yields), float32 and uint8 batches of 4096 and 728 rows (728 = the
+    largest single execute of a real 1080p frame).  Best and median of 9 after two warm-up calls.
+    Beside every figure the ceiling that bounds it and the fraction reached: the host reading the caller's array
+    (float64 / float32: `host_read_GBps`, measured by tools/ubench/host_pack_bw.cpp: 16 threads on the rows' memory node
+    narrow float64 at 288 GB/s) or host stores into device memory over PCIe (`link_GBps`: 43 GB/s through the BAR,
+    tools/ubench/bar_write_bw.cpp) for the 16 KiB a row occupies on the wire.  `caller_GBps` = bytes of the caller's array
+    per second (float rows holding integer pixel values cross PCIe as uint8 after the exact narrowing, so this is NOT the
+    PCIe rate)."""
     from pyfaceanalysis_amd import synth
     from pyfaceanalysis_amd.flow import Flow
+    host_read, link = 288.0, 43.0
     out = {}
     f = Flow.from_blob(blob, output_dtype=np.float64)
-    for dt in (np.float64, np.uint8):
+    for dt in (np.float64, np.float32, np.uint8):
         for n in (4096, 728):
             x = synth.make_subimages(n, SIDE, dtype=dt)
             f.execute(x[:64], n_cols=N_COLS)
             f.execute(x, n_cols=N_COLS)
-            best = 1e9
-            for _ in range(5):
+            ts = []
+            for _ in range(9):
                 t0 = time.perf_counter()
                 f.execute(x, n_cols=N_COLS)
-                best = min(best, time.perf_counter() - t0)
-            out["%s_n%d" % (np.dtype(dt).name, n)] = {"sub_images_per_s": n / best, "ms_per_call": best * 1e3, "caller_GBps": x.nbytes / best / 1e9}
+                ts.append(time.perf_counter() - t0)
+            best, med = min(ts), sorted(ts)[len(ts) // 2]
+            t_read = x.nbytes / (host_read * 1e9) if dt != np.uint8 else 0.0
+            t_link = n * SIDE * SIDE / (link * 1e9)
+            floor = max(t_read, t_link)
+            out["%s_n%d" % (np.dtype(dt).name, n)] = {
+                "sub_images_per_s": n / best, "ms_per_call": best * 1e3, "ms_per_call_median": med * 1e3, "caller_GBps": x.nbytes / best / 1e9,
+                "wire_GBps": n * SIDE * SIDE / best / 1e9, "ceiling": "host read" if t_read >= t_link else "PCIe (host stores into device memory)",
+                "ceiling_ms": floor * 1e3, "frac_of_ceiling": floor / best}
     f.close()
-    out["note"] = "Flow.execute(host ndarray) -> host float64 (N, 20): includes packing, H2D, kernels, D2H; never `value`"
+    out["ceilings"] = {"host_read_GBps": host_read, "link_GBps": link,
+                       "source": "tools/ubench/host_pack_bw.cpp, tools/ubench/bar_write_bw.cpp (profiles/r04_host_path.txt)"}
+    out["note"] = "Flow.execute(host ndarray) -> host float64 (N, 20): includes packing, PCIe, kernels, features back; never `value`"
     return out
 
 

@@ -1,13 +1,18 @@
 // C ABI (include/higsfa.h): flow handle, host/device execute, profiling.
 #include <algorithm>
 #include <atomic>
+#include <cctype>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
 #include <thread>
 
+#include <sys/syscall.h>
+#include <unistd.h>
+
 #include "hg_common.hpp"
-#include "hg_hostpool.hpp"
+#include "hg_hostpipe.hpp"
 
 namespace {
 
@@ -40,71 +45,107 @@ namespace {
 
 using hg::HostPool;      // hg_hostpool.hpp
 
-}  // namespace
+constexpr int NB = 6;        // passes in flight per replica: input / feature buffers rotate over NB slots
+constexpr int NC = 2;        // copy queues: pieces alternate between them, so that the fixed cost of one copy (~13 us on this
+                             // runtime: queue packet, completion signal) runs under the transfer of the other
+constexpr int MK = 128;      // events that mark points in the copy queue (ring reuse of calls longer than the pinned ring)
 
-namespace hg {
-// hg_hostpack.cpp (plain C++, built with g++ so that it can carry AVX2 clones): row of wide values -> uint8 when every
-// value is an integer 0..255; false otherwise.
-bool narrow_row_f64(const double* src, uint8_t* dst, int64_t n);
-bool narrow_row_f32(const float* src, uint8_t* dst, int64_t n);
-}  // namespace hg
+// NUMA node that holds the page of p (get_mempolicy(MPOL_F_NODE | MPOL_F_ADDR)); -1 when the kernel does not say
+int node_of_address(const void* p) {
+    int node = -1;
+    if (syscall(SYS_get_mempolicy, &node, nullptr, 0ul, (unsigned long)p, 3ul) != 0) return -1;
+    return node;
+}
 
-namespace {
+// NUMA node the device hangs off (/sys/bus/pci/devices/<bus id>/numa_node); -1 when unknown
+int node_of_device(int device) {
+    char bdf[64] = {0}, path[160];
+    if (hipDeviceGetPCIBusId(bdf, sizeof bdf, device) != hipSuccess) return -1;
+    for (char* c = bdf; *c; ++c) *c = (char)tolower(*c);
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bdf);
+    int node = -1;
+    if (FILE* f = fopen(path, "r")) {
+        if (fscanf(f, "%d", &node) != 1) node = -1;
+        fclose(f);
+    }
+    return node;
+}
 
 // One execution context: the executor on one device with its streams and staging buffers.
 struct Replica {
     int device = -1;
     std::unique_ptr<hg::Executor> exec;
-    hipStream_t compute = nullptr, copy = nullptr;
-    void* hx[2] = {nullptr, nullptr};      // pinned host staging, two slots
-    void* hy[2] = {nullptr, nullptr};
-    size_t hx_bytes = 0, hy_bytes = 0;
-    hg::DevBuf dx[2], dy[2];
-    hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+    hipStream_t compute = nullptr, copy[NC] = {};
+    void* ring = nullptr;                  // pinned host staging the packers write and the copy queue reads (hg_hostpipe.hpp)
+    size_t ring_bytes = 0;
+    void* hy[NB] = {};      // pinned: features of a pass on their way back
+    size_t hy_bytes = 0;
+    hg::DevBuf dx[NB], dy[NB];
+    hipEvent_t ev_h2d[NB][NC] = {}, ev_out[NB] = {};
+    hipEvent_t mk_ev[MK] = {};             // created on first use
+    std::unique_ptr<HostPool> pool;        // shard replicas pack with a few threads of their own; null: the process-wide pool
+    bool large_bar = false;                // the host can store into this device's memory (hipDeviceAttributeIsLargeBar)
 
     void create(int dev) {
         HG_HIP(hipSetDevice(dev));
         exec->to_device();
         HG_HIP(hipStreamCreateWithFlags(&compute, hipStreamNonBlocking));
-        HG_HIP(hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
-        for (int b = 0; b < 2; ++b) {
-            HG_HIP(hipEventCreateWithFlags(&ev_h2d[b], hipEventDisableTiming));
+        for (int c = 0; c < NC; ++c) HG_HIP(hipStreamCreateWithFlags(&copy[c], hipStreamNonBlocking));
+        for (int b = 0; b < NB; ++b) {
+            for (int c = 0; c < NC; ++c) HG_HIP(hipEventCreateWithFlags(&ev_h2d[b][c], hipEventDisableTiming));
             HG_HIP(hipEventCreateWithFlags(&ev_out[b], hipEventDisableTiming));
         }
         HG_HIP(hipDeviceSynchronize());
+        int lb = 0;
+        large_bar = hipDeviceGetAttribute(&lb, hipDeviceAttributeIsLargeBar, dev) == hipSuccess && lb != 0;
         device = dev;
     }
-    void need_pinned(size_t xb, size_t yb) {
-        if (xb > hx_bytes) {
-            for (int b = 0; b < 2; ++b) {
-                if (hx[b]) (void)hipHostFree(hx[b]);
-                hx[b] = nullptr;
-                HG_HIP(hipHostMalloc(&hx[b], xb, hipHostMallocDefault));
-            }
-            hx_bytes = xb;
+    void need_pinned(size_t ring_b, size_t yb) {
+        if (ring_b > ring_bytes) {
+            if (ring) (void)hipHostFree(ring);
+            ring = nullptr;
+            ring_bytes = 0;
+            HG_HIP(hipHostMalloc(&ring, ring_b, hipHostMallocDefault));
+            ring_bytes = ring_b;
         }
         if (yb > hy_bytes) {
-            for (int b = 0; b < 2; ++b) {
+            for (int b = 0; b < NB; ++b) {
                 if (hy[b]) (void)hipHostFree(hy[b]);
                 hy[b] = nullptr;
-                HG_HIP(hipHostMalloc(&hy[b], yb, hipHostMallocDefault));
             }
+            hy_bytes = 0;
+            for (int b = 0; b < NB; ++b) HG_HIP(hipHostMalloc(&hy[b], yb, hipHostMallocDefault));
             hy_bytes = yb;
         }
     }
     void destroy() {
         if (device < 0 || hipSetDevice(device) != hipSuccess) return;
-        for (int b = 0; b < 2; ++b) {
-            if (hx[b]) (void)hipHostFree(hx[b]);
+        if (ring) (void)hipHostFree(ring);
+        ring = nullptr;
+        ring_bytes = 0;
+        for (int b = 0; b < NB; ++b) {
             if (hy[b]) (void)hipHostFree(hy[b]);
-            if (ev_h2d[b]) (void)hipEventDestroy(ev_h2d[b]);
+            for (int c = 0; c < NC; ++c) {
+                if (ev_h2d[b][c]) (void)hipEventDestroy(ev_h2d[b][c]);
+                ev_h2d[b][c] = nullptr;
+            }
             if (ev_out[b]) (void)hipEventDestroy(ev_out[b]);
             dx[b].free();
             dy[b].free();
-            hx[b] = hy[b] = nullptr;
+            hy[b] = nullptr;
+            ev_out[b] = nullptr;
+        }
+        hy_bytes = 0;
+        for (auto& e : mk_ev) {
+            if (e) (void)hipEventDestroy(e);
+            e = nullptr;
         }
         if (compute) (void)hipStreamDestroy(compute);
-        if (copy) (void)hipStreamDestroy(copy);
+        for (int c = 0; c < NC; ++c) {
+            if (copy[c]) (void)hipStreamDestroy(copy[c]);
+            copy[c] = nullptr;
+        }
+        compute = nullptr;
         if (exec) exec->release();
         device = -1;
     }
@@ -122,6 +163,8 @@ struct hg_flow {
     int64_t flops = 0;
     bool profiling = false, force_generic = false;
     bool narrow = true;                  // HIGSFA_NO_NARROW, read once in hg_flow_load
+    bool direct = true;                  // HIGSFA_HOST_DIRECT=0 (read once in hg_flow_load): host rows through the pinned ring and the copy
+                                         // queues even where the host could store into device memory
     std::vector<hipEvent_t> events;
     std::vector<hg::StageProfile> prof;
 
@@ -191,112 +234,273 @@ void run_on_device(hg_flow* f, const void* x, int x_dtype, int64_t n, int64_t ld
 }
 
 
-// Host rows -> device -> host rows through one replica: chunks of rows are packed into pinned staging slot b
-// (narrowed to uint8 when every value is an integer 0..255), copied on the copy stream while the previous chunk's
-// kernels run on the compute stream, and the features come back through a pinned slot as well.
-//   slot reuse: hx[b] after ev_h2d[b] (its H2D done); dx[b] / dy[b] / hy[b] after ev_out[b] (kernels + D2H of the
-//   chunk that used the slot done).
-void run_host_rows_impl(hg_flow* f, Replica& rep, const void* x, int x_dtype, int64_t n, int64_t ldx, void* y, int y_dtype, int64_t y_cols,
-                        int64_t ldy, bool use_pool) {
-    const size_t xs = hg::dtype_size(x_dtype), ys = hg::dtype_size(y_dtype);
-    const int64_t in_dim = f->root->in_dim;
-    // ~32 MiB of caller bytes per chunk (>= 256 rows): small enough to pipeline a 4096-row float64 batch in 16 chunks,
-    // large enough that a chunk's kernels are past their launch-latency floor
-    // uint8 rows cannot be narrowed and need no packing: they go straight from the caller's memory (the runtime stages pageable
-    // memory itself; a second host copy into our pinned slot would only add a pass over the data) in 16 MiB chunks, so that the
-    // copy of chunk i+1 still overlaps the kernels of chunk i
-    const bool direct = x_dtype == HG_U8;
-    int64_t chunk = std::max<int64_t>(256, ((direct ? 16ll : 32ll) << 20) / (in_dim * (int64_t)xs));
-    chunk = std::min(chunk, n);
-    chunk = (chunk + 15) / 16 * 16;
-    const size_t x_slot = (size_t)chunk * in_dim * xs, y_slot = (size_t)chunk * y_cols * ys;
-    rep.need_pinned(direct ? 0 : x_slot, y_slot);
-    for (int b = 0; b < 2; ++b) {
-        rep.dx[b].alloc(x_slot);
-        rep.dy[b].alloc(y_slot);
+// Device side of the host pipeline (hg_hostpipe.hpp): the copy queue fills the input buffer of pass P (slot P % NB) piece by
+// piece, the compute queue runs the pass and brings its features back through a pinned slot.
+//   slot reuse: dx[b] after ev_out[b] (kernels of the pass that used it: the copy queue waits); dy[b] in queue order;
+//   hy[b] after the host has taken the features of the pass that used it (unpack, which waits for ev_out[b]).
+struct HipSink final : hg::PipeSink {
+    hg_flow* f;
+    Replica& rep;
+    char* y;
+    int y_dtype;
+    int64_t y_cols, ldy, in_dim;
+    size_t ys;
+    int wire_dtype = HG_U8;
+    size_t row_wire = 0;
+    int pass_base = 0;                                     // passes launched by earlier run_pipe invocations of this call
+    int64_t row_base = 0;                                  // first row of this invocation within the call
+    std::vector<std::pair<int64_t, int64_t>> pass_rows;    // (first row, rows) of every pass launched, in the call's rows
+    int unpacked = 0;                                      // passes whose features are in the caller's y
+    uint64_t mk_seq = 0, mk_done = 0;
+    int n_queues = NC;                                     // HIGSFA_COPY_QUEUES=1: every piece through one queue
+    uint64_t n_copies = 0;
+    int waited[NC], used[NC], last_queue = 0;              // per copy queue: last pass whose buffer it has waited for / it has copied into
+    bool timed = false;                                    // HIGSFA_HOST_TRACE: timed events around every pass
+    std::vector<hipEvent_t> t_ev;                          // base, then (begin, end) per pass
+
+    ~HipSink() {
+        for (auto e : t_ev) (void)hipEventDestroy(e);
     }
-    rep.exec->reserve(chunk);
-    const bool try_narrow = x_dtype != HG_U8 && f->narrow;
-    HostPool& pool = HostPool::get();
-    const int64_t n_chunks = (n + chunk - 1) / chunk;
-    auto unpack = [&](int64_t ci) {      // features of chunk ci: pinned slot -> caller rows
-        const int b = (int)(ci & 1);
-        const int64_t r0 = ci * chunk, m = std::min(chunk, n - r0);
+    void stamp() {
+        hipEvent_t e = nullptr;
+        HG_HIP(hipEventCreate(&e));
+        t_ev.push_back(e);
+        HG_HIP(hipEventRecord(e, rep.compute));
+    }
+    HipSink(hg_flow* f_, Replica& r, void* y_, int ydt, int64_t yc, int64_t ldy_, int64_t in_dim_)
+        : f(f_), rep(r), y((char*)y_), y_dtype(ydt), y_cols(yc), ldy(ldy_), in_dim(in_dim_), ys(hg::dtype_size(ydt)) {
+        static const char* q = getenv("HIGSFA_COPY_QUEUES");
+        if (q) n_queues = std::max(1, std::min(NC, atoi(q)));
+        for (int c = 0; c < NC; ++c) waited[c] = used[c] = -1;
+    }
+
+    void unpack(int P) {      // features of pass P: pinned slot -> caller rows
+        const int b = P % NB;
         HG_HIP(hipEventSynchronize(rep.ev_out[b]));
+        const int64_t r0 = pass_rows[(size_t)P].first, m = pass_rows[(size_t)P].second;
         const char* src = (const char*)rep.hy[b];
-        char* dst = (char*)y + (size_t)r0 * ldy * ys;
+        char* dst = y + (size_t)r0 * ldy * ys;
         const size_t row = (size_t)y_cols * ys;
         if (ldy == y_cols) memcpy(dst, src, row * m);
         else for (int64_t r = 0; r < m; ++r) memcpy(dst + (size_t)r * ldy * ys, src + (size_t)r * row, row);
-    };
-    for (int64_t ci = 0; ci < n_chunks; ++ci) {
-        const int b = (int)(ci & 1);
-        const int64_t r0 = ci * chunk, m = std::min(chunk, n - r0);
-        if (ci >= 2) {
-            unpack(ci - 2);                               // frees hy[b] (and tells us dx[b] / dy[b] are free)
-            if (!direct) HG_HIP(hipEventSynchronize(rep.ev_h2d[b]));   // hx[b] has left the host
-        }
-        // ---- pack (host threads), overlapping the GPU work of chunk ci - 1
-        const char* xsrc = (const char*)x + (size_t)r0 * ldx * xs;
-        int sent_dtype = x_dtype;
-        if (direct) {
-            if (ci >= 2) HG_HIP(hipStreamWaitEvent(rep.copy, rep.ev_out[b], 0));
-            HG_HIP(hipMemcpy2DAsync(rep.dx[b].p, (size_t)in_dim * xs, xsrc, (size_t)ldx * xs, (size_t)in_dim * xs, (size_t)m, hipMemcpyHostToDevice, rep.copy));
-            HG_HIP(hipEventRecord(rep.ev_h2d[b], rep.copy));
-        }
-        if (try_narrow) {
-            std::atomic<int> ok{1};
-            const int tasks = (int)std::min<int64_t>(m, use_pool ? 4 * pool.size() : 1);
-            auto body = [&](int t) {
-                const int64_t a = m * t / tasks, e = m * (t + 1) / tasks;
-                for (int64_t r = a; r < e && ok.load(std::memory_order_relaxed); ++r) {
-                    const bool good = x_dtype == HG_F64
-                                          ? hg::narrow_row_f64((const double*)(xsrc + (size_t)r * ldx * xs), (uint8_t*)rep.hx[b] + (size_t)r * in_dim, in_dim)
-                                          : hg::narrow_row_f32((const float*)(xsrc + (size_t)r * ldx * xs), (uint8_t*)rep.hx[b] + (size_t)r * in_dim, in_dim);
-                    if (!good) ok.store(0, std::memory_order_relaxed);
-                }
-            };
-            if (use_pool) pool.parallel_for(tasks, body);
-            else body(0);
-            if (ok.load()) sent_dtype = HG_U8;
-        }
-        const size_t ss = hg::dtype_size(sent_dtype);
-        if (sent_dtype == x_dtype && !direct) {      // as given: rows copied into the pinned slot (strided source allowed)
-            const int tasks = (int)std::min<int64_t>(m, use_pool ? 4 * pool.size() : 1);
-            auto body = [&](int t) {
-                const int64_t a = m * t / tasks, e = m * (t + 1) / tasks;
-                if (ldx == in_dim) memcpy((char*)rep.hx[b] + (size_t)a * in_dim * xs, xsrc + (size_t)a * in_dim * xs, (size_t)(e - a) * in_dim * xs);
-                else for (int64_t r = a; r < e; ++r) memcpy((char*)rep.hx[b] + (size_t)r * in_dim * xs, xsrc + (size_t)r * ldx * xs, (size_t)in_dim * xs);
-            };
-            if (use_pool) pool.parallel_for(tasks, body);
-            else body(0);
-        }
-        // ---- copy stream: H2D once the slot's previous consumer is done
-        if (!direct) {
-            if (ci >= 2) HG_HIP(hipStreamWaitEvent(rep.copy, rep.ev_out[b], 0));
-            HG_HIP(hipMemcpyAsync(rep.dx[b].p, rep.hx[b], (size_t)m * in_dim * ss, hipMemcpyHostToDevice, rep.copy));
-            HG_HIP(hipEventRecord(rep.ev_h2d[b], rep.copy));
-        }
-        // ---- compute stream: kernels, features back
-        HG_HIP(hipStreamWaitEvent(rep.compute, rep.ev_h2d[b], 0));
-        run_on_device(f, rep.dx[b].p, sent_dtype, m, in_dim, rep.dy[b].p, y_dtype, y_cols, y_cols, rep.compute, &rep);
-        HG_HIP(hipMemcpyAsync(rep.hy[b], rep.dy[b].p, (size_t)m * y_cols * ys, hipMemcpyDeviceToHost, rep.compute));
-        HG_HIP(hipEventRecord(rep.ev_out[b], rep.compute));
     }
-    if (n_chunks >= 2) unpack(n_chunks - 2);
-    unpack(n_chunks - 1);
+    void unpack_upto(int P) {      // every launched pass below P
+        for (; unpacked < P; ++unpacked) unpack(unpacked);
+    }
+    void copy(int pass, int64_t dst_row, const void* src, int64_t rows) override {
+        const int P = pass_base + pass, b = P % NB, c = (int)(n_copies++ % (uint64_t)n_queues);
+        if (waited[c] < P) {      // first piece of this pass on this queue: dx[b] is free once the kernels of pass P - NB are done
+            if (P >= NB) HG_HIP(hipStreamWaitEvent(rep.copy[c], rep.ev_out[b], 0));
+            waited[c] = P;
+        }
+        HG_HIP(hipMemcpyAsync((char*)rep.dx[b].p + (size_t)dst_row * row_wire, src, (size_t)rows * row_wire, hipMemcpyHostToDevice, rep.copy[c]));
+        used[c] = P;
+        last_queue = c;
+    }
+    void launch(int pass, int64_t r0, int64_t rows) override {
+        const int P = pass_base + pass, b = P % NB;
+        for (int c = 0; c < n_queues; ++c) {
+            if (used[c] != P) continue;      // no piece of this pass went through queue c
+            HG_HIP(hipEventRecord(rep.ev_h2d[b][c], rep.copy[c]));
+            HG_HIP(hipStreamWaitEvent(rep.compute, rep.ev_h2d[b][c], 0));
+        }
+        if (P >= NB) unpack_upto(P - NB + 1);
+        if (timed) stamp();
+        run_on_device(f, rep.dx[b].p, wire_dtype, rows, in_dim, rep.dy[b].p, y_dtype, y_cols, y_cols, rep.compute, &rep);
+        if (timed) stamp();
+        HG_HIP(hipMemcpyAsync(rep.hy[b], rep.dy[b].p, (size_t)rows * y_cols * ys, hipMemcpyDeviceToHost, rep.compute));
+        HG_HIP(hipEventRecord(rep.ev_out[b], rep.compute));
+        pass_rows.emplace_back(row_base + r0, rows);
+    }
+    uint64_t mark() override {
+        const uint64_t s = ++mk_seq;
+        hipEvent_t& e = rep.mk_ev[s % MK];
+        if (!e) HG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        else
+            while (s > MK && mk_done < s - MK) {      // the slot still carries mark s - MK, which nobody has seen completed yet
+                HG_HIP(hipEventSynchronize(rep.mk_ev[(mk_done + 1) % MK]));      // in order: the marks sit on two queues
+                ++mk_done;
+            }
+        HG_HIP(hipEventRecord(e, rep.copy[last_queue]));      // the queue the piece just went through
+        return s;
+    }
+    bool finished(int pass) override {      // direct mode: only asked about launched passes, before their slot's event is recorded again
+        const hipError_t q = hipEventQuery(rep.ev_out[(pass_base + pass) % NB]);
+        if (q == hipSuccess) return true;
+        if (q != hipErrorNotReady) HG_HIP(q);
+        (void)hipGetLastError();
+        return false;
+    }
+    bool reached(uint64_t m) override {      // polled oldest first
+        if (m <= mk_done) return true;
+        const hipError_t q = hipEventQuery(rep.mk_ev[m % MK]);
+        if (q == hipSuccess) {
+            mk_done = m;
+            return true;
+        }
+        if (q != hipErrorNotReady) HG_HIP(q);
+        (void)hipGetLastError();      // not ready is not an error: clear the sticky code
+        return false;
+    }
+};
+
+// What the pass planner assumes (hg_hostpipe.hpp plan_passes): microseconds per row until a row is on the device, and the cost
+// of a pass.  Rates from tools/ubench/host_pack_bw.cpp on the pool's boxes (two sockets of EPYC 9575F, PCIe Gen5 x16): 16 threads
+// on the rows' memory node narrow float64 at 288 GB/s of caller bytes, pinned memory crosses PCIe at 50 - 57 GB/s in 4 - 64 MiB
+// copies; a pass costs ~8 us per launch plus its issued FLOPs at the ~80 TFLOP/s the fused plan sustains (one call
+// = 100 us + 0.107 us per row on U11L-128).  The plan only has to be sensible, not exact: it decides pass boundaries, never results.
+hg::PassModel pass_model(const hg_flow* f, const Replica& rep, size_t row_src, size_t row_wire, bool narrowing, int workers, int64_t max_pass_rows, bool direct) {
+    hg::PassModel m;
+    const double pack_Bpus = narrowing ? std::min(250e3, 20e3 * workers) : std::min(100e3, 10e3 * workers);      // bytes per microsecond
+    m.arrive_us_per_row = std::max((double)row_src / pack_Bpus, (double)row_wire / (direct ? 42e3 : 50e3));
+    m.lat_us = direct ? 10 : 30;
+    m.c0_us = 8.0 * rep.exec->n_stages();
+    const int64_t padded = rep.exec->padded_flops_per_row();
+    m.c1_us_per_row = rep.exec->plan_kind() == HG_PLAN_FUSED ? (double)(padded > 0 ? padded : f->flops) / 80e6 : (double)f->flops / 1e6;
+    m.max_pass_rows = max_pass_rows;
+    static const char* price = getenv("HIGSFA_PASS_PRICE");      // experiments: microseconds one more pass must save (hg_hostpipe.hpp)
+    if (price) m.per_pass_us = atof(price);
+    return m;
+}
+
+// HIGSFA_PASSES=a,b,c (experiments): explicit pass sizes for calls of exactly a + b + c rows
+std::vector<int64_t> passes_from_env(int64_t n, int64_t max_pass_rows) {
+    std::vector<int64_t> out;
+    static const char* e = getenv("HIGSFA_PASSES");
+    if (!e) return out;
+    int64_t sum = 0;
+    for (const char* p = e; *p;) {
+        char* q = nullptr;
+        const long long v = strtoll(p, &q, 10);
+        if (q == p || v <= 0 || v > max_pass_rows) return {};
+        out.push_back(v);
+        sum += v;
+        p = *q == ',' ? q + 1 : q;
+    }
+    if (sum != n) out.clear();
+    return out;
+}
+
+// Host rows -> device -> host rows through one replica (hg_hostpipe.hpp has the picture).  Values that are all integers 0..255
+// (what images_asarray produces, face_analysis.py:786) cross PCIe as uint8 after an exact narrowing; the first row that is
+// anything else switches the rest of the call to the caller's own type.
+void run_host_rows_impl(hg_flow* f, Replica& rep, const void* x, int x_dtype, int64_t n, int64_t ldx, void* y, int y_dtype, int64_t y_cols,
+                        int64_t ldy) {
+    const size_t xs = hg::dtype_size(x_dtype), ys = hg::dtype_size(y_dtype);
+    const int64_t in_dim = f->root->in_dim;
+    const size_t row_src = (size_t)ldx * xs, row_given = (size_t)in_dim * xs, row_u8 = (size_t)in_dim;
+    bool narrow = x_dtype != HG_U8 && f->narrow;
+    // pass buffers: 16 MiB of wire bytes each (1024 uint8 rows of a 128x128 net), at least 16 rows of the caller's type;
+    // pinned ring: the call's wire bytes up to 64 MiB, at least 64 rows
+    const size_t pass_bytes = std::max<size_t>((size_t)16 << 20, 16 * row_given);
+    auto pass_rows_for = [&](size_t row_wire) { return std::max<int64_t>(16, std::min<int64_t>(65536, (int64_t)(pass_bytes / row_wire) / 16 * 16)); };
+    const int64_t widest_pass = std::min<int64_t>((n + 15) / 16 * 16, pass_rows_for(narrow ? row_u8 : row_given));
+    // Large-BAR devices (every MI355X of this pool): the packers store wire rows straight into the pass's input buffer in HBM —
+    // tools/ubench/bar_write_bw.cpp: 42 - 44 GB/s from four or more threads of either socket, a kernel launched afterwards sees
+    // the bytes also in a buffer an earlier kernel has read — and there is no pinned ring and no copy queue: in the staged form
+    // the DMA engine ran at 25 - 45 GB/s beside the packers' memory traffic and trailed them by up to 0.4 ms at the end of a call.
+    const bool direct = rep.large_bar && f->direct;
+    const size_t ring_want = direct ? 0 : std::max<size_t>(64 * row_given, std::min<size_t>((size_t)64 << 20, (size_t)n * row_given));
+    rep.need_pinned(ring_want, (size_t)widest_pass * y_cols * ys);
+    for (int b = 0; b < NB; ++b) {
+        rep.dx[b].alloc(std::min<size_t>(pass_bytes, (size_t)((n + 15) / 16 * 16) * row_given));
+        rep.dy[b].alloc((size_t)widest_pass * y_cols * ys);
+    }
+    rep.exec->reserve(widest_pass);
+
+    HostPool* pool = rep.pool ? rep.pool.get() : &HostPool::get();
+    const bool inline_pack = (size_t)n * row_given < ((size_t)1 << 20);      // under 1 MiB: the calling thread packs, nobody is woken
+    if (!inline_pack) {
+        const int a = node_of_address(x), b = node_of_address((const char*)x + (size_t)(n - 1) * row_src + row_given - 1);
+        pool->bind_to_node(a == b ? a : -1);
+    }
+    HipSink sink(f, rep, y, y_dtype, y_cols, ldy, in_dim);
+    static const bool want_trace = getenv("HIGSFA_HOST_TRACE") != nullptr;
+    hg::PipeTrace trace;
+    trace.t0 = std::chrono::steady_clock::now();
+    if (want_trace) {
+        sink.timed = true;
+        sink.stamp();
+    }
+    for (int64_t r0 = 0; r0 < n;) {
+        hg::PipeJob J;
+        J.x = (const char*)x + (size_t)r0 * row_src;
+        J.elem = (int)xs;
+        J.n = n - r0;
+        J.ldx = ldx;
+        J.in_dim = in_dim;
+        J.narrow = narrow;
+        J.ring = (uint8_t*)rep.ring;
+        J.ring_bytes = rep.ring_bytes;
+        const size_t row_wire = narrow ? row_u8 : row_given;
+        const int64_t max_pass = pass_rows_for(row_wire);
+        J.passes = passes_from_env(J.n, max_pass);
+        if (J.passes.empty()) J.passes = hg::plan_passes(J.n, pass_model(f, rep, row_src, row_wire, narrow, inline_pack ? 1 : pool->size(), max_pass, direct));
+        static const char* pk = getenv("HIGSFA_PIECE_KIB");      // experiments: "min,max" KiB of wire bytes per copy
+        size_t piece_lo = (size_t)1 << 20, piece_hi = (size_t)8 << 20;
+        if (pk) {
+            unsigned long a = 0, b = 0;
+            if (sscanf(pk, "%lu,%lu", &a, &b) == 2 && a > 0 && b >= a) piece_lo = a << 10, piece_hi = b << 10;
+        }
+        J.piece_min = std::max<int64_t>(1, (int64_t)(piece_lo / row_wire));
+        J.piece_max = std::max<int64_t>(J.piece_min, (int64_t)(piece_hi / row_wire));
+        J.copy_us_per_row = (double)row_wire / 57e3;
+        static const char* tkb = getenv("HIGSFA_TICKET_KIB");      // experiments
+        J.ticket_bytes = tkb ? (size_t)atol(tkb) << 10 : narrow ? (size_t)512 << 10 : (size_t)128 << 10;
+        if (direct && !narrow) J.max_workers = 6;      // copying into device memory: the link is full with four to six writers
+        if (direct) {
+            J.direct_slots = NB;
+            for (size_t p = 0; p < J.passes.size(); ++p) J.pass_dst.push_back((uint8_t*)rep.dx[(sink.pass_rows.size() + p) % NB].p);
+        }
+        sink.wire_dtype = narrow ? HG_U8 : x_dtype;
+        sink.row_wire = row_wire;
+        sink.pass_base = (int)sink.pass_rows.size();
+        sink.row_base = r0;
+        if (want_trace) J.trace = &trace;
+        const hg::PipeResult res = hg::run_pipe(J, sink, pool, inline_pack);
+        r0 += res.rows_done;
+        if (!res.narrow_failed) break;
+        narrow = false;      // a value that is not an integer 0..255: the rest of the call travels in the caller's type
+        for (int c = 0; c < NC; ++c) HG_HIP(hipStreamSynchronize(rep.copy[c]));      // pieces of the abandoned pass must not land after the new ones
+    }
+    const float t_sub = want_trace ? trace.now() : 0.f;
+    sink.unpack_upto((int)sink.pass_rows.size());
     rep.exec->check_errors();      // everything has completed: a poll that ran out in one of the kernels fails THIS call
+    if (want_trace) {      // the LAST invocation's timeline (a call that fell through to the wide type shows its wide part)
+        float pack_end = 0, pack_first = 1e30f;
+        for (float t : trace.ticket_done) {
+            pack_end = std::max(pack_end, t);
+            if (t >= 0) pack_first = std::min(pack_first, t);
+        }
+        fprintf(stderr, "[host trace] memory nodes: caller rows %d, pinned ring %d, device %d; packers %d; %s\n", node_of_address(x), rep.ring ? node_of_address(rep.ring) : -1,
+                node_of_device(rep.device), pool->size(), direct ? "direct stores into device memory" : "pinned ring + copy queues");
+        fprintf(stderr, "[host trace] n %lld dtype %d: %zu tickets, first done %.0f us, last done %.0f us; submitted %.0f us; call %.0f us\n", (long long)n, x_dtype,
+                trace.ticket_done.size(), pack_first, pack_end, t_sub, trace.now());
+        size_t pi = 0;
+        for (size_t k = 0; k < trace.passes.size(); ++k) {
+            fprintf(stderr, "[host trace]   pass %zu (%lld rows): pieces", k, (long long)trace.passes[k].rows);
+            for (; pi < trace.pieces.size() && trace.pieces[pi].pass == (int)k; ++pi)
+                fprintf(stderr, " %lld@%.0f+%.0f", (long long)trace.pieces[pi].rows, trace.pieces[pi].t_begin, trace.pieces[pi].t_end - trace.pieces[pi].t_begin);
+            float g0 = 0, g1 = 0;
+            if (sink.t_ev.size() >= 2 * k + 3) {
+                (void)hipEventElapsedTime(&g0, sink.t_ev[0], sink.t_ev[2 * k + 1]);
+                (void)hipEventElapsedTime(&g1, sink.t_ev[0], sink.t_ev[2 * k + 2]);
+            }
+            fprintf(stderr, "; launch call %.0f .. %.0f us; kernels on the device %.0f .. %.0f us\n", trace.passes[k].t_begin, trace.passes[k].t_end, g0 * 1e3f, g1 * 1e3f);
+        }
+    }
 }
 
 // A call that fails half-way (a HIP error, a launch refused) must not leave copies and kernels in flight on the replica's
-// staging slots: the next call on the replica starts at chunk 0 / 1, which reuse the slots without waiting for an event, and
-// need_pinned may free and reallocate them.  Drain both streams before the error leaves.
+// staging buffers: the next call on the replica reuses them from the start without waiting for an event, and need_pinned may
+// free and reallocate them.  Drain both streams before the error leaves.
 void run_host_rows(hg_flow* f, Replica& rep, const void* x, int x_dtype, int64_t n, int64_t ldx, void* y, int y_dtype, int64_t y_cols,
-                   int64_t ldy, bool use_pool) {
+                   int64_t ldy) {
     try {
-        run_host_rows_impl(f, rep, x, x_dtype, n, ldx, y, y_dtype, y_cols, ldy, use_pool);
+        run_host_rows_impl(f, rep, x, x_dtype, n, ldx, y, y_dtype, y_cols, ldy);
     } catch (...) {
-        if (rep.copy) (void)hipStreamSynchronize(rep.copy);
+        for (int c = 0; c < NC; ++c)
+            if (rep.copy[c]) (void)hipStreamSynchronize(rep.copy[c]);
         if (rep.compute) (void)hipStreamSynchronize(rep.compute);
         throw;
     }
@@ -328,6 +532,7 @@ int hg_flow_load(const void* blob, size_t nbytes, int flags, hg_flow** out) {
         f->flops = hg::tree_flops(*f->root);
         f->force_generic = flags & 1;
         f->narrow = getenv("HIGSFA_NO_NARROW") == nullptr;
+        f->direct = !(getenv("HIGSFA_HOST_DIRECT") && atoi(getenv("HIGSFA_HOST_DIRECT")) == 0);
         if (!(flags & 1)) f->exec = hg::make_fused_executor(*f->root, &f->fused_reject);
         else f->fused_reject = "generic plan forced by caller";
         if (!f->exec) f->exec = hg::make_generic_executor(*f->root);
@@ -417,7 +622,7 @@ int hg_flow_execute(hg_flow* f, const void* x, int x_dtype, int64_t n, int64_t l
         f->need_device();
         f->set_device();
         if (n == 0) return;
-        run_host_rows(f, f->main, x, x_dtype, n, ldx, y, y_dtype, y_cols, ldy, true);
+        run_host_rows(f, f->main, x, x_dtype, n, ldx, y, y_dtype, y_cols, ldy);
     });
 }
 
@@ -457,6 +662,14 @@ int hg_flow_execute_sharded(hg_flow* f, const void* x, int x_dtype, int64_t n, i
             if (!rep.exec) rep.exec = hg::make_generic_executor(*f->root);
             rep.create(devs[r]);
         }
+        // several blocks pack at the same time: each replica gets its share of the usable threads as a pool of its own (the
+        // process-wide pool runs one region at a time); a single block uses the process-wide pool
+        const int share = std::max(1, std::min(hg::usable_cpus(), 16) / n_devices);
+        for (int r = 0; r < n_devices; ++r) {
+            Replica& rep = *f->shards[r];
+            if (n_devices == 1) rep.pool.reset();
+            else if (!rep.pool || rep.pool->size() != share) rep.pool.reset(new HostPool(share));
+        }
         // contiguous row blocks of ceil(n / n_devices) rows (pyfaceanalysis_amd/sharded.py shard_bounds), one host thread per
         // block; every block lands in the caller's y at its own rows, which IS the gather (host memory, no peer copy)
         const int64_t per = (n + n_devices - 1) / n_devices;
@@ -472,7 +685,7 @@ int hg_flow_execute_sharded(hg_flow* f, const void* x, int x_dtype, int64_t n, i
                     Replica& rep = *f->shards[r];
                     HG_HIP(hipSetDevice(rep.device));
                     run_host_rows(f, rep, (const char*)x + (size_t)lo * ldx * xs, x_dtype, hi - lo, ldx, (char*)y + (size_t)lo * ldy * ys,
-                                  y_dtype, y_cols, ldy, n_devices == 1);
+                                  y_dtype, y_cols, ldy);
                 } catch (const hg::Error& e) {
                     codes[r] = e.code;
                     errs[r] = e.what();

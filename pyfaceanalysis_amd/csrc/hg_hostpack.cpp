@@ -8,7 +8,9 @@
 // values above 255, NaN / Inf): the caller then sends the row block in its own type.
 #include <immintrin.h>
 
+#include <algorithm>
 #include <cstdint>
+#include <cstring>
 
 namespace hg {
 
@@ -77,6 +79,32 @@ __attribute__((target("avx2"))) bool narrow_f32_avx2(const float* src, uint8_t* 
 const bool kHaveAvx2 = __builtin_cpu_supports("avx2");
 
 }  // namespace
+
+// memcpy whose destination is write-combined device memory (the host path's direct mode): non-temporal 32-byte stores for the
+// aligned middle, plain copies for the edges.
+__attribute__((target("avx2"))) static void stream_copy_avx2(uint8_t* d, const uint8_t* s, size_t n) {
+    const size_t head = std::min<size_t>(n, (32 - ((uintptr_t)d & 31)) & 31);
+    memcpy(d, s, head);
+    d += head, s += head, n -= head;
+    size_t i = 0;
+    for (; i + 128 <= n; i += 128) {
+        const __m256i a = _mm256_loadu_si256((const __m256i*)(s + i)), b = _mm256_loadu_si256((const __m256i*)(s + i + 32)),
+                      c = _mm256_loadu_si256((const __m256i*)(s + i + 64)), e = _mm256_loadu_si256((const __m256i*)(s + i + 96));
+        _mm256_stream_si256((__m256i*)(d + i), a);
+        _mm256_stream_si256((__m256i*)(d + i + 32), b);
+        _mm256_stream_si256((__m256i*)(d + i + 64), c);
+        _mm256_stream_si256((__m256i*)(d + i + 96), e);
+    }
+    for (; i + 32 <= n; i += 32) _mm256_stream_si256((__m256i*)(d + i), _mm256_loadu_si256((const __m256i*)(s + i)));
+    memcpy(d + i, s + i, n - i);
+}
+
+void stream_copy(void* dst, const void* src, size_t bytes) {
+    if (kHaveAvx2) stream_copy_avx2((uint8_t*)dst, (const uint8_t*)src, bytes);
+    else memcpy(dst, src, bytes);
+}
+
+void store_fence() { _mm_sfence(); }
 
 bool narrow_row_f64(const double* src, uint8_t* dst, int64_t n) {
     return kHaveAvx2 ? narrow_f64_avx2(src, dst, n) : narrow_scalar(src, dst, n);

@@ -1,5 +1,7 @@
-"""GPU: the ndarray-in / ndarray-out call (hg_flow_execute, FaceDetectUpdated.py:699) through its pinned,
-double-buffered, exactness-checked staging, and the same call over several replicas (hg_flow_execute_sharded)."""
+"""GPU: the ndarray-in / ndarray-out call (hg_flow_execute, FaceDetectUpdated.py:699) through the host pipeline
+(hg_hostpipe.hpp: packers narrowing exactly / copying, straight into device memory on large-BAR devices or through the
+pinned ring and the copy queues; passes sized by the planner), and the same call over several replicas
+(hg_flow_execute_sharded)."""
 import numpy as np
 import pytest
 
@@ -16,20 +18,23 @@ def rel_err(y, ref):
     return float(np.abs(np.asarray(y, dtype=np.float64) - ref).max() / np.abs(ref).max())
 
 
-def test_pipelined_chunks_narrowing_and_fallthrough(native_lib, nets, monkeypatch):
-    """More rows than two staging slots hold (chunks of 32 MiB of caller bytes: 16 384 rows of this 256-pixel net in
-    float64), so slots are reused.  Integer pixels cross PCIe as uint8; a chunk holding anything else (a fraction, a
-    negative, 256, NaN) goes in its own type; either way every row equals what the plain uint8 / float64 call gives."""
+@pytest.mark.parametrize("direct", ["1", "0"])
+def test_pipelined_chunks_narrowing_and_fallthrough(native_lib, nets, monkeypatch, direct):
+    """Several passes per call (70 000 rows of this 256-pixel net: the pass buffers hold 65 536 uint8 rows, 8192 float64
+    rows), so pass buffers are reused.  Integer pixels cross PCIe as uint8; from the first row that holds anything else (a
+    fraction, a negative, 256, NaN) the rest of the call goes in its own type; either way every row equals what the plain
+    uint8 / float64 call gives.  Both transports: stores into device memory (large BAR) and pinned ring + copy queues."""
     nodes = nets("T5L-16")
-    n = 70000                                   # 5 chunks in float64, 3 in float32
+    n = 70000
     xi = synth.make_subimages(n, 16, dtype=np.uint8)
+    monkeypatch.setenv("HIGSFA_HOST_DIRECT", direct)          # read once, when a flow is loaded
     flow = Flow(nodes)
     y8 = flow.execute(xi)
     idx = np.arange(0, n, 997)
     assert rel_err(y8[idx], oracle.execute_flow(nodes, xi[idx])) <= TOL
     for dt in (np.float64, np.float32):
         assert np.array_equal(flow.execute(xi.astype(dt)), y8)
-    # a non-image value in chunk 1 and in the last chunk: those chunks fall through, nothing else changes
+    # a non-image value in the middle and in the last row: the call falls through to the wide type there, no other row changes
     xf = xi.astype(np.float64)
     xf[20000, 5] = 17.5
     xf[n - 1, 255] = -3.0
@@ -52,17 +57,35 @@ def test_pipelined_chunks_narrowing_and_fallthrough(native_lib, nets, monkeypatc
     flow.close()
 
 
-def test_u11l_host_path_all_dtypes(native_lib, nets):
+@pytest.mark.parametrize("direct", ["1", "0"])
+def test_u11l_host_path_all_dtypes(native_lib, nets, monkeypatch, direct):
     """The reference's own call shape: float64 ndarray of 128x128 pixel values in, float64 features out, at the
-    largest batch a real frame produces (N = 728)."""
+    largest batch a real frame produces (N = 728, SURVEY.md §6: two passes), at sizes around the planner's pass
+    boundaries and at a size that needs more passes than there are pass buffers (6): every call bit-equal to the rows of
+    the device-resident call on the same pixels, whatever the type handed over."""
     nodes = nets("U11L-128")
-    x8 = synth.make_subimages(728, 128, dtype=np.uint8)
+    monkeypatch.setenv("HIGSFA_HOST_DIRECT", direct)
     flow = Flow(nodes)
-    y = flow.execute(x8.astype(np.float64))
+    x8 = synth.make_subimages(5000, 128, dtype=np.uint8)
+    y = flow.execute(x8[:728].astype(np.float64))
     assert y.dtype == np.float64 and y.shape == (728, 60)
-    assert np.array_equal(y, flow.execute(x8)) and np.array_equal(y, flow.execute(x8.astype(np.float32)))
+    assert np.array_equal(y, flow.execute(x8[:728])) and np.array_equal(y, flow.execute(x8[:728].astype(np.float32)))
     idx = np.arange(0, 728, 29)
     assert rel_err(y[idx], oracle.execute_flow(nodes, x8[idx])) <= TOL
+    import torch
+    dev = torch.device("cuda", 0)
+    xd = torch.from_numpy(x8).to(dev)
+    yd = torch.empty((5000, 60), dtype=torch.float64, device=dev)
+    flow.execute_device(xd.data_ptr(), np.uint8, 5000, 16384, yd.data_ptr(), np.float64, 60, 60, stream=torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize()
+    ref = yd.cpu().numpy()
+    for n, dt in ((1, np.float64), (7, np.uint8), (17, np.float32), (300, np.float64), (1023, np.uint8), (1025, np.float64), (5000, np.float64), (5000, np.uint8)):
+        assert np.array_equal(flow.execute(x8[:n].astype(dt)), ref[:n]), (n, dt)
+    xf = x8[:3000].astype(np.float32)
+    xf[1500, 77] = 0.25                          # falls through to float32 from the pass that holds row 1500
+    yf = flow.execute(xf)
+    keep = np.arange(3000) != 1500
+    assert np.array_equal(yf[keep], ref[:3000][keep]) and not np.array_equal(yf[1500], ref[1500])
     flow.close()
 
 

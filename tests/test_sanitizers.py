@@ -82,3 +82,26 @@ def test_host_pool_under_tsan(tmp_path):
     if "FATAL: ThreadSanitizer" in out and "unexpected memory mapping" in out:
         pytest.skip("TSAN cannot run in this container (address-space layout): " + out[-200:])
     assert r.returncode == 0 and "WARNING: ThreadSanitizer" not in out and "bad 0 0 thrown 1 sum 4950" in out, out[-3000:]
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_host_pipeline_plain_and_under_tsan(tmp_path):
+    """The host half of hg_flow_execute (hg_hostpipe.hpp: tickets, pinned ring or direct destinations, pieces, passes, the
+    fall-through from exact narrowing to the caller's type, the pass planner) with a memcpy sink in the place of the GPU
+    whose copies and passes complete late: 281 seeded cases, every row's sum computed from the wire rows the sink received.
+    Once as a plain build (must pass), once under ThreadSanitizer (skipped where TSAN cannot run)."""
+    srcs = [os.path.join(ROOT, "tests", "tsan_pipe_driver.cpp"), os.path.join(ROOT, "pyfaceanalysis_amd", "csrc", "hg_hostpack.cpp")]
+    inc = "-I" + os.path.join(ROOT, "pyfaceanalysis_amd", "csrc")
+    exe = tmp_path / "pipe_driver"
+    subprocess.run(["g++", "-std=c++17", "-O2", "-pthread", inc] + srcs + ["-o", str(exe)], check=True)
+    r = subprocess.run([str(exe)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0 and b"bad 0" in r.stdout, r.stdout.decode(errors="replace")[-2000:]
+    texe = tmp_path / "pipe_driver_tsan"
+    b = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-pthread", inc] + srcs + ["-o", str(texe)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if b.returncode != 0:
+        pytest.skip("TSAN build not possible here: " + b.stdout.decode(errors="replace")[-300:])
+    r = subprocess.run([str(texe)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1:second_deadlock_stack=1"))
+    out = r.stdout.decode(errors="replace")
+    if "FATAL: ThreadSanitizer" in out and "unexpected memory mapping" in out:
+        pytest.skip("TSAN cannot run in this container (address-space layout): " + out[-200:])
+    assert r.returncode == 0 and "WARNING: ThreadSanitizer" not in out and "bad 0" in out, out[-3000:]
