@@ -348,43 +348,6 @@ def train_leg(dev, n=100_000):
             "max_rel_err_eigenvalues_vs_scipy": worst_val, "max_err_eigenvectors_vs_scipy": worst_vec, "nodes_checked": 3, "budget": 1e-5}
 
 
-def bf16x3_leg(blob, nodes, dev, rows, steps):
-    """EXPERIMENT, not the headline and not its arithmetic: the same step with HIGSFA_BF16X3=1 — layers 3..7 with every fp32
-    product replaced by six bf16 products on v_mfma_f32_16x16x32_bf16 (fp32 accumulate; hg_fused_b3.hip).
-    Reported with its own error against the oracle so that the trade can be judged; `dtype` of the bench line stays f32 and
-    describes the default plan only."""
-    import torch
-    from oracle import mdp_restate
-    from pyfaceanalysis_amd import synth
-    from pyfaceanalysis_amd.flow import Flow
-    os.environ["HIGSFA_BF16X3"] = "1"          # read once, when the plan is built
-    try:
-        flow = Flow.from_blob(blob, device=dev.index, output_dtype=np.float32)
-        flow.reserve(rows)
-    finally:
-        os.environ.pop("HIGSFA_BF16X3", None)
-    n_exp = sum("HIGSFA_BF16X3" in ln for ln in flow.describe().splitlines())
-    xh = synth.make_subimages(rows, SIDE, dtype=np.float32)
-    x = torch.from_numpy(xh).to(dev)
-    y = torch.empty((rows, N_COLS), dtype=torch.float32, device=dev)
-    st = torch.cuda.current_stream(dev)
-
-    def run(k):
-        for _ in range(k):
-            flow.execute_device(x.data_ptr(), np.float32, rows, x.shape[1], y.data_ptr(), np.float32, N_COLS, N_COLS, stream=st.cuda_stream)
-        torch.cuda.synchronize(dev)
-    run(max(100, steps // 4))
-    t0 = time.perf_counter()
-    run(steps)
-    dt = (time.perf_counter() - t0) / steps
-    ref = mdp_restate.execute_flow(nodes, xh[:64].astype(np.float64))[:, :N_COLS]
-    err = float(np.abs(y[:64].cpu().numpy() - ref).max() / np.abs(ref).max())
-    flow.close()
-    return {"arithmetic": "layers 3-7: six bf16 products per fp32 product (operands split h + m + l on the fly / on the host), fp32 accumulate; "
-                          "all other layers exact fp32 as in the headline", "layers_on_split_bf16": n_exp, "sub_images_per_s": rows / dt,
-            "ms_per_step": dt * 1e3, "max_rel_err_vs_oracle": err, "note": "labelled side experiment (HIGSFA_BF16X3=1); never the default plan"}
-
-
 def uniform_leg(flow, nodes, dev, rows, steps):
     """SURVEY.md §8d's stress variant of the input: pure uniform random pixels (no 3x3 low-pass), same step, same checks."""
     import torch
@@ -517,7 +480,24 @@ def main():
     # the step is pyfaceanalysis_amd.sharded.ShardedFlow.step — the class tests/test_sharded_gloo.py runs over gloo:
     # flow.execute_device on this rank's block, then (N > 1) the RCCL all-gather of the first 20 features on a side
     # stream, double-buffered so that the gather of step i runs under the kernels of step i + 1
-    sf = ShardedFlow.for_flow(flow, N_COLS, rows, dev, collective=distributed)
+    gather_events = None
+    if distributed:
+        # Before anything is timed: the overlapped gather against a blocking one, on inputs that change from step to step and differ
+        # between ranks (x is rank-seeded), every rank comparing every rank's block.  First with the device-scope hand-off event
+        # (3-4 us per step cheaper); if any rank sees a mismatch, all ranks fall back to the ordinary event and check again.
+        x_alts = [x, torch.roll(x, shifts=1 + rank, dims=0), torch.flip(x, dims=(0,))]
+        sf = ShardedFlow.for_flow(flow, N_COLS, rows, dev, collective=True, light_events=True)
+        if sf.verify_against_blocking_gather(x_alts, steps=6):
+            gather_events = "device-scope hand-off event; 6 steps on changing inputs equal to a blocking all-gather on every rank"
+        else:
+            sf.close()
+            sf = ShardedFlow.for_flow(flow, N_COLS, rows, dev, collective=True, light_events=False)
+            if not sf.verify_against_blocking_gather(x_alts, steps=6):
+                raise SystemExit("bench.py: the overlapped all-gather does not reproduce a blocking one (rank %d)" % rank)
+            gather_events = "system-scope hand-off event (the device-scope form FAILED verification on this node)"
+        del x_alts
+    else:
+        sf = ShardedFlow.for_flow(flow, N_COLS, rows, dev, collective=False)
     stream = sf.stream
 
     def step():
@@ -622,8 +602,10 @@ def main():
         # parity of the timed configuration on a slice of the batch (oracle = checker only)
         from oracle import mdp_restate
         m = 64
-        ref = mdp_restate.execute_flow(nodes, x_host[:m].astype(np.float64))[:, :N_COLS]
-        got = y[:m].cpu().numpy().astype(np.float64)
+        check_rows = np.arange(m) * (rows // m) if rows >= m else np.arange(rows)      # rows 0, rows/64, 2 rows/64, ...: every part of the batch
+        m = len(check_rows)
+        ref = mdp_restate.execute_flow(nodes, x_host[check_rows].astype(np.float64))[:, :N_COLS]
+        got = y.cpu().numpy()[check_rows].astype(np.float64)
         max_rel = float(np.abs(got - ref).max() / np.abs(ref).max())
         # worst case per column over the first 20: each column against ITS OWN largest reference magnitude
         per_col = np.abs(got - ref).max(axis=0) / np.abs(ref).max(axis=0)
@@ -710,10 +692,11 @@ def main():
                                    "first %d slow features out%s" % (rows, in_dt.name, N_COLS,
                                                                      ", RCCL all-gather of the features overlapped with the next step" if distributed else ""),
                        "settle_ms": round(settle_ms, 1), "rows_per_gpu": rows, "global_rows": total_rows, "plan": "fused" if info.plan_kind == 1 else "generic",
-                       "parallelism": "row-shard x%d" % world},
+                       "parallelism": "row-shard x%d" % world, **({"gather_events": gather_events} if gather_events else {})},
             "max_rel_err_vs_oracle": max_rel,
             "max_rel_err_first20_percol": {"worst": float(per_col.max()), "worst_column": int(per_col.argmax()),
                                            "per_column": [float("%.3e" % v) for v in per_col], "rows_checked": m,
+                                           "row_set": "rows k * %d, k = 0 .. %d (strided over the whole batch)" % (max(1, rows // 64), m - 1),
                                            "definition": "max_i |y[i,c] - ref[i,c]| / max_i |ref[i,c]| per column c"},
             "flops_per_subimage": flops_row, "padded_flops_per_subimage": int(info.padded_flops_per_row),
             "roofline": roof,
@@ -721,18 +704,23 @@ def main():
         if in_flight is not None:
             out["batches_in_flight"] = in_flight
         if not args.no_frame and world == 1 and info.plan_kind == 1 and args.node_kind == "pca_exp_sfa":
-            fr = frame_leg(flow, dev, flow_factory=lambda: Flow.from_blob(blob, device=local_rank, output_dtype=np.float32))
-            out["frames_per_s"] = fr["frames_per_s"]                 # one frame at a time (latency figure)
-            if "frames_in_flight" in fr:
-                out["frames_per_s_4_in_flight"] = fr["frames_in_flight"]["4"]["frames_per_s"]
-            out["frame_leg"] = fr
+            try:
+                fr = frame_leg(flow, dev, flow_factory=lambda: Flow.from_blob(blob, device=local_rank, output_dtype=np.float32))
+                out["frames_per_s"] = fr["frames_per_s"]                 # one frame at a time (latency figure)
+                if "frames_in_flight" in fr:
+                    out["frames_per_s_4_in_flight"] = fr["frames_in_flight"]["4"]["frames_per_s"]
+                out["frame_leg"] = fr
+            except Exception as exc:      # noqa: BLE001
+                out["frame_leg"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         if not args.no_extra_legs and world == 1 and info.plan_kind == 1 and args.node_kind == "pca_exp_sfa" and rows == ROWS_PER_GPU:
             leg_steps = max(50, min(args.steps, 400))
-            out["uniform_input"] = uniform_leg(flow, nodes, dev, rows, leg_steps)
-            out["u11l_64"] = u11l_64_leg(dev, rows, leg_steps)
-            out["host_path"] = host_path_leg(blob)
-            out["train_leg"] = train_leg(dev)
-            out["bf16x3_experiment"] = bf16x3_leg(blob, nodes, dev, rows, leg_steps)
+            # figures beside the headline: a leg that fails reports its error and leaves the headline line intact
+            for key, leg in (("uniform_input", lambda: uniform_leg(flow, nodes, dev, rows, leg_steps)), ("u11l_64", lambda: u11l_64_leg(dev, rows, leg_steps)),
+                             ("host_path", lambda: host_path_leg(blob)), ("train_leg", lambda: train_leg(dev))):
+                try:
+                    out[key] = leg()
+                except Exception as exc:      # noqa: BLE001
+                    out[key] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(nodes)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]

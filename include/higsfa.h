@@ -128,6 +128,11 @@ int hg_flow_execute_device(hg_flow* f, const void* x_dev, int x_dtype, int64_t n
  * They order device work only — nothing the host reads may depend on them.  `ev` is an opaque handle (hipEvent_t),
  * streams are hipStream_t of the calling thread's current device. */
 int hg_event_create(void** ev);
+/* The same on a stated device, whatever the calling thread's current device is (which it leaves unchanged), and with the
+ * choice of scope: device_scope 0 creates an ordinary (hipEventDisableTiming) event whose record also publishes to system
+ * scope — what pyfaceanalysis_amd/sharded.py uses for the hand-off that carries DATA to the collective unless a run on more
+ * than one GPU has verified the device-scope form (bench.py does that before it times anything). */
+int hg_event_create_on(void** ev, int device, int device_scope);
 void hg_event_destroy(void* ev);
 int hg_event_record(void* ev, void* stream);
 int hg_stream_wait_event(void* stream, void* ev);

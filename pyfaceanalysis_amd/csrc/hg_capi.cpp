@@ -710,6 +710,23 @@ int hg_event_create(void** ev) {
     });
 }
 
+int hg_event_create_on(void** ev, int device, int device_scope) {
+    return guarded([&] {
+        if (!ev) hg::fail(HG_ERR_ARG, "null event pointer");
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) hg::fail(HG_ERR_DEVICE, "no HIP device available");
+        if (device < 0 || device >= count) hg::fail(HG_ERR_DEVICE, "device %d out of range (0..%d)", device, count - 1);
+        int cur = -1;
+        HG_HIP(hipGetDevice(&cur));
+        HG_HIP(hipSetDevice(device));      // an event belongs to the device that is current when it is created
+        hipEvent_t e = nullptr;
+        const hipError_t rc = hipEventCreateWithFlags(&e, hipEventDisableTiming | (device_scope ? hipEventDisableSystemFence : 0));
+        if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
+        HG_HIP(rc);
+        *ev = (void*)e;
+    });
+}
+
 void hg_event_destroy(void* ev) {
     if (ev) (void)hipEventDestroy((hipEvent_t)ev);
 }

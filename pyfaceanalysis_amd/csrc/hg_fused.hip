@@ -49,7 +49,6 @@ struct FusedOptions {
     uint32_t wq_start = 0;        // HIGSFA_WQ_START: initial value of the tile-queue counters (tests: wrap-around)
     bool no_wgq = false;          // HIGSFA_NO_WGQ: k_stage01d with one tile queue per layer-1 node instead of one per chunk (2-3 % faster, +29 % HBM bytes)
     bool no_direct = false;       // HIGSFA_NO_DIRECT: front kernel always stages the input rows through LDS (k_stage01p)
-    bool bf16x3 = false;          // HIGSFA_BF16X3=1: EXPERIMENTAL split-bf16 operands for the 4x4-tile middle layers (hg_fused_b3.hip); never the default
     int tail_max = 3;             // HIGSFA_TAIL: most layers k_tail fuses at the top of the hierarchy (0: off — per-layer launches + k_unpack)
     bool no_fspec = false;        // HIGSFA_NO_FSPEC: front kernel without the compile-time (identity, abs-power) expansion
     int splitm_max_nodes = 4;     // experiments: HIGSFA_SPLITM_MAX
@@ -73,7 +72,6 @@ struct FusedOptions {
         if (const char* e = getenv("HIGSFA_SPLITM_MAX")) o.splitm_max_nodes = atoi(e);
         if (const char* e = getenv("HIGSFA_SPLITM_WGS")) o.splitm_max_wgs = atoi(e);
         if (const char* e = getenv("HIGSFA_SHAPES")) o.shape_variant = atoi(e);
-        if (const char* e = getenv("HIGSFA_BF16X3")) o.bf16x3 = atoi(e) != 0;
         if (const char* e = getenv("HIGSFA_TAIL")) o.tail_max = std::max(0, std::min(atoi(e), kMaxTail));
         return o;
     }
@@ -887,10 +885,6 @@ struct HostStage {
     int p_max = 0, s_max = 0;   // widest first / second affine of the layer (real outputs)
     bool rem4 = false;          // last tiles of both affines in 4x4 form (k_stage REM instantiations)
     bool pack_out = false;      // output: the remainder tiles of four sibling nodes share one block (StageParams::pack_base)
-    bool b3 = false;            // EXPERIMENTAL (HIGSFA_BF16X3): this stage also has a split-bf16 weight image and runs on k_stage_b3
-    int np1 = 0;                // its K-slabs (pairs of K-blocks) of the first affine
-    std::vector<uint32_t> w3;   // [node][slab][m-tile][part h/m/l][lane][4 dwords = 8 bf16]
-    DevBuf d_w3;
     std::vector<int32_t> pack_slot;
     DevBuf d_pack_slot;
     bool has_exp = false, contig4 = false, vec_ok = false;
@@ -1215,7 +1209,6 @@ public:
         for (auto& hs : stages_)      // k_tail reads 8 K-block entries at once from a node's first: 8 spare ones behind the last node's
             if (!hs.kb1tab.empty()) hs.kb1tab.resize(hs.kb1tab.size() + 16, 0);
         plan_tail();
-        if (opt_.bf16x3) plan_b3();
     }
 
     int plan_kind() const override { return HG_PLAN_FUSED; }
@@ -1244,7 +1237,6 @@ public:
             s.d_afrag.upload(s.afrag.data(), s.afrag.size() * 4);
             s.d_bias.upload(s.bias.data(), s.bias.size() * 4);
             if (!s.kb1tab.empty()) s.d_kb1tab.upload(s.kb1tab.data(), s.kb1tab.size() * 4);
-            if (!s.w3.empty()) s.d_w3.upload(s.w3.data(), s.w3.size() * 4);
             if (!s.gcol.empty()) s.d_gcol.upload(s.gcol.data(), s.gcol.size() * 4);
             if (!s.etab.empty()) s.d_etab.upload(s.etab.data(), s.etab.size() * 4);
             if (!s.pack_slot.empty()) s.d_pack_slot.upload(s.pack_slot.data(), s.pack_slot.size() * 4);
@@ -1539,12 +1531,6 @@ public:
                 // hierarchy at any batch size, and EVERY ordinary layer while its grid is small enough to be resident at once —
                 // a k_stage workgroup first copies 27-52 KiB of weights into LDS (5 us), which small batches never earn back
                 // (N = 16: 92 -> 70 us per call, N = 340: 137 -> 129, N = 1024: the same; grids of more than ~500 workgroups: k_stage wins)
-                if (s.b3 && n_tiles >= 16) {      // EXPERIMENTAL split-bf16 operands (HIGSFA_BF16X3=1)
-                    launch_b3(P, s.d_w3.p, s.np1, n_tiles, n_cus_, st);
-                    std::swap(cur, nxt);
-                    if (ev) HG_HIP(hipEventRecord(ev[e++], st));
-                    continue;
-                }
                 const int T_sm = n_tiles >= 2 * 256 / std::max(1, s.n_nodes) ? 2 : 1;
                 const int64_t wgs_sm = (int64_t)((n_tiles + T_sm - 1) / T_sm) * s.n_nodes;
                 if (s.kind == 0 && (!s.rem4 || s.mt1 == s.mt2) && (s.rem4 || !s.pack_out) && s.mt1 * s.nf <= 8 &&
@@ -1690,7 +1676,7 @@ public:
         d_col_of_.free();
         for (auto& s : stages_) {
             s.d_afrag.free(); s.d_bias.free(); s.d_kb1tab.free(); s.d_chunks.free();
-            s.d_runs.free(); s.d_piece.free(); s.d_koff.free(); s.d_kmean.free(); s.d_kcol.free(); s.d_gcol.free(); s.d_etab.free(); s.d_pack_slot.free(); s.d_w3.free();
+            s.d_runs.free(); s.d_piece.free(); s.d_koff.free(); s.d_kmean.free(); s.d_kcol.free(); s.d_gcol.free(); s.d_etab.free(); s.d_pack_slot.free();
         }
         cap_rows_ = 0;
     }
@@ -2362,78 +2348,6 @@ private:
         if (blocks > 0x7fffffffll) fail(HG_ERR_ARG, "batch too large");
         set_lds_limit(fn, lds_bytes);
         hipLaunchKernelGGL(fn, (unsigned)blocks, nw * 64, lds_bytes, st, P);
-    }
-
-    // EXPERIMENTAL (HIGSFA_BF16X3=1): split-bf16 weight images for the ordinary 4x4-tile layers with an
-    // (identity, |x|^p) expansion that k_tail does not take — layers 3..7 of the preset nets.  Built from the fp32 A fragments:
-    // slab p of the first affine = K-blocks 2p, 2p+1 (slots 0..3 / 4..7 of every lane); second affine: slab (function, half)
-    // = expanded z tiles 2 half, 2 half + 1 of that function.  Every fp32 weight w becomes h = bf16(w), m = bf16(w - h),
-    // l = bf16(w - h - m), round to nearest even.
-    static uint32_t bf16_rne(float f) {
-        uint32_t u;
-        memcpy(&u, &f, 4);
-        if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;      // NaN stays NaN
-        u += 0x7fffu + ((u >> 16) & 1u);
-        return u >> 16;
-    }
-    static float bf16_to_f32(uint32_t h) {
-        const uint32_t u = h << 16;
-        float f;
-        memcpy(&f, &u, 4);
-        return f;
-    }
-    void plan_b3() {
-        const int ns = (int)stages_.size();
-        for (int si = fuse01_ ? 2 : 1; si < (tail_begin_ >= 0 ? tail_begin_ : ns); ++si) {
-            HostStage& hs = stages_[si];
-            if (hs.kind != 0 || hs.from_x || !hs.has_exp || hs.rem4 || hs.pack_out || hs.mt1 != 4 || hs.mt2 != 4 || hs.nf != 2 ||
-                hs.kb1 > 8 || hs.funcs[0].kind != E_IDENTITY || hs.funcs[1].kind != E_ABS_POW)
-                continue;
-            hs.np1 = (hs.kb1 + 1) / 2;
-            const int slabs = hs.np1 + 4;
-            hs.w3.assign((size_t)hs.n_nodes * slabs * 4 * 3 * 256, 0u);
-            for (int ni = 0; ni < hs.n_nodes; ++ni) {
-                const float* wnode = hs.afrag.data() + (size_t)ni * hs.node_blocks * 256;
-                const float* w2 = wnode + (size_t)hs.kb1 * hs.mt1 * 256;
-                uint32_t* out = hs.w3.data() + (size_t)ni * slabs * 4 * 3 * 256;
-                for (int sl = 0; sl < slabs; ++sl)
-                    for (int mt = 0; mt < 4; ++mt)
-                        for (int lane = 0; lane < 64; ++lane) {
-                            float v[8];
-                            for (int s8 = 0; s8 < 8; ++s8) {
-                                const int half = s8 >> 2, r = s8 & 3;
-                                const float* blk = nullptr;
-                                if (sl < hs.np1) {
-                                    const int kb = 2 * sl + half;
-                                    if (kb < hs.kb1) blk = wnode + ((size_t)kb * hs.mt1 + mt) * 256;
-                                } else {
-                                    const int q = sl - hs.np1, fi = q >> 1, mt1i = 2 * (q & 1) + half;
-                                    blk = w2 + ((size_t)(mt1i * hs.nf + fi) * hs.mt2 + mt) * 256;
-                                }
-                                v[s8] = blk ? blk[lane * 4 + r] : 0.f;
-                            }
-                            uint32_t part[3][8];
-                            for (int s8 = 0; s8 < 8; ++s8) {
-                                const uint32_t h = bf16_rne(v[s8]);
-                                const float r1 = v[s8] - bf16_to_f32(h);
-                                const uint32_t m = bf16_rne(r1);
-                                const float r2 = r1 - bf16_to_f32(m);
-                                part[0][s8] = h;
-                                part[1][s8] = m;
-                                part[2][s8] = bf16_rne(r2);
-                            }
-                            for (int pt = 0; pt < 3; ++pt)
-                                for (int d = 0; d < 4; ++d)
-                                    out[(((size_t)sl * 4 + mt) * 3 + pt) * 256 + lane * 4 + d] = part[pt][2 * d] | (part[pt][2 * d + 1] << 16);
-                        }
-            }
-            if (b3_lds_bytes(hs.np1, hs.bias_floats) > 160 * 1024) {
-                hs.w3.clear();
-                continue;
-            }
-            hs.b3 = true;
-            hs.name += "  [EXPERIMENTAL HIGSFA_BF16X3: six bf16 products per fp32 product on v_mfma_f32_16x16x32_bf16 — not the fp32 arithmetic of the default plan]";
-        }
     }
 
     // The suffix of the stage list that k_tail runs as one launch: ordinary layers (no remainder / packed tiles, K-blocks of the

@@ -337,9 +337,6 @@ size_t tail_lds_bytes(const TailParams& P, int T);
 int tail_waves(const TailParams& P);
 void launch_tail(const TailParams& P, int T, hipStream_t st);
 
-// EXPERIMENTAL split-bf16 stage kernel (hg_fused_b3.hip; HIGSFA_BF16X3=1)
-size_t b3_lds_bytes(int np1, int bias_floats);
-void launch_b3(const StageParams& P, const void* w3, int np1, int n_tiles, int n_cus, hipStream_t st);
 
 typedef void (*StageFn)(StageParams);
 typedef void (*StageFn2)(StageParams, StageParams);

@@ -98,7 +98,10 @@ def _is_numeric_state(v):
     return isinstance(v, np.ndarray) and v.dtype.kind in "fiuc"
 
 
-def convert_node(obj, igsfa_lr_input=None, ignore_attrs=(), pair_prodsadj_reading=None):
+MATRIX_ORIENTATIONS = ("n@R.T", "n@R")
+
+
+def convert_node(obj, igsfa_lr_input=None, ignore_attrs=(), pair_prodsadj_reading=None, igsfa_matrix_orientation=None):
     """One pickled node (stub) -> a pyfaceanalysis_amd.nodes object.
 
     ``igsfa_lr_input``: "scaled" or "unscaled" — which slow features a pickled iGSFANode's ``lr_node`` reads
@@ -106,10 +109,14 @@ def convert_node(obj, igsfa_lr_input=None, ignore_attrs=(), pair_prodsadj_readin
     scaling; there is no default because the reference's source for it is not available.
     ``ignore_attrs``: names of extra numeric attributes of iGSFANode stubs to accept unconsumed.
     ``pair_prodsadj_reading``: "offset" or "band" — the meaning of ``pair_prodsadj{k}_ex`` (``nodes.pair_prodsadj_ex``);
-    required as soon as a pickled expansion names such a function, no default for the same reason."""
+    required as soon as a pickled expansion names such a function, no default for the same reason.
+    ``igsfa_matrix_orientation``: "n@R.T" or "n@R" — how the QR-scaling matrix ``R`` of an iGSFANode with
+    ``slow_feature_scaling_method="QR_decomposition"`` meets the normalised slow features n (s = n @ R.T or s = n @ R); R is
+    square, so the dimensions cannot tell, and the rule lives in cuicuilco @9bfd242: required for such nodes, no default."""
     if obj is None:
         return None
-    kw = dict(igsfa_lr_input=igsfa_lr_input, ignore_attrs=ignore_attrs, pair_prodsadj_reading=pair_prodsadj_reading)
+    kw = dict(igsfa_lr_input=igsfa_lr_input, ignore_attrs=ignore_attrs, pair_prodsadj_reading=pair_prodsadj_reading,
+              igsfa_matrix_orientation=igsfa_matrix_orientation)
     name = _cls(obj)
     if name in ("PCANode", "WhiteningNode"):
         i, o = _dims(obj)
@@ -155,7 +162,15 @@ def convert_node(obj, igsfa_lr_input=None, ignore_attrs=(), pair_prodsadj_readin
                              "than guess its execute" % (method, sorted(m for m in _IGSFA_SCALING if m)))
         scaling, magn, matrix = _IGSFA_SCALING[method], None, None
         if scaling == "matrix":
-            matrix = np.asarray(_get(obj, "R"), dtype=np.float64).T            # s = n @ R.T  [K]
+            if igsfa_matrix_orientation not in MATRIX_ORIENTATIONS:
+                raise ValueError("iGSFANode with QR_decomposition scaling: state igsfa_matrix_orientation='n@R.T' or 'n@R' (how the "
+                                 "pickled square matrix R meets the normalised slow features) — the rule lives in cuicuilco @9bfd242, "
+                                 "which is not available here, and the two give different features")
+            matrix = np.asarray(_get(obj, "R"), dtype=np.float64)
+            if matrix.ndim != 2 or matrix.shape[0] != matrix.shape[1]:
+                raise ValueError("iGSFANode: QR scaling matrix R of shape %r is not square" % (matrix.shape,))
+            if igsfa_matrix_orientation == "n@R.T":
+                matrix = matrix.T                                              # nodes.iGSFANode computes s = n @ scaling_matrix
         elif scaling == "per_column":
             magn = np.asarray(_get(obj, "magn_n_sfa_x"), dtype=np.float64).reshape(-1)
         else:
@@ -210,14 +225,14 @@ def convert_flow_object(flow_obj, **kw):
     return out
 
 
-def load_flow_pickle(path, igsfa_lr_input=None, ignore_attrs=(), pair_prodsadj_reading=None):
+def load_flow_pickle(path, igsfa_lr_input=None, ignore_attrs=(), pair_prodsadj_reading=None, igsfa_matrix_orientation=None):
     return convert_flow_object(load_stub_pickle(path), igsfa_lr_input=igsfa_lr_input, ignore_attrs=ignore_attrs,
-                               pair_prodsadj_reading=pair_prodsadj_reading)
+                               pair_prodsadj_reading=pair_prodsadj_reading, igsfa_matrix_orientation=igsfa_matrix_orientation)
 
 
-def pickle_to_blob(path, igsfa_lr_input=None, ignore_attrs=(), pair_prodsadj_reading=None):
+def pickle_to_blob(path, igsfa_lr_input=None, ignore_attrs=(), pair_prodsadj_reading=None, igsfa_matrix_orientation=None):
     return flow_to_blob(load_flow_pickle(path, igsfa_lr_input=igsfa_lr_input, ignore_attrs=ignore_attrs,
-                                         pair_prodsadj_reading=pair_prodsadj_reading))
+                                         pair_prodsadj_reading=pair_prodsadj_reading, igsfa_matrix_orientation=igsfa_matrix_orientation))
 
 
 if __name__ == "__main__":
@@ -229,6 +244,9 @@ if __name__ == "__main__":
                     help="which slow features the iGSFA linear reconstruction reads (no default: see nodes.iGSFANode)")
     ap.add_argument("--pair-prodsadj-reading", choices=N.PAIR_READINGS, default=None,
                     help="meaning of pair_prodsadj{k}_ex: x_i*x_{i+k} only, or offsets 0..k-1 (no default: see nodes.pair_prodsadj_ex)")
+    ap.add_argument("--igsfa-matrix-orientation", choices=MATRIX_ORIENTATIONS, default=None,
+                    help="QR_decomposition scaling of iGSFA nodes: s = n @ R.T or s = n @ R (no default: R is square)")
     a = ap.parse_args()
     with open(a.out, "wb") as fh:
-        fh.write(pickle_to_blob(a.pickle, igsfa_lr_input=a.igsfa_lr_input, pair_prodsadj_reading=a.pair_prodsadj_reading))
+        fh.write(pickle_to_blob(a.pickle, igsfa_lr_input=a.igsfa_lr_input, pair_prodsadj_reading=a.pair_prodsadj_reading,
+                                igsfa_matrix_orientation=a.igsfa_matrix_orientation))

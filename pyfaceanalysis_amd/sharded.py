@@ -47,13 +47,21 @@ class ShardedFlow(object):
     ``collective``: issue the all-gather (default: whenever a process group is initialised).
 
     On a GPU the gather of step i runs on a side stream under the kernels of step i+1 (two feature
-    buffers, events in both directions — device-scope events of the library, ``hg_event_*``: a default event's
-    record writes the caches back to system scope and held the next launch up by 13 us); ``step`` returns the tensor the gather writes, valid once
+    buffers, events in both directions); ``step`` returns the tensor the gather writes, valid once
     ``wait()`` has returned or ``done_event(i)`` of that step has been waited for, and ONLY until step
     i + 2 is enqueued, which writes the same buffer again: a consumer that needs it longer copies it.
+
+    ``light_events``: scope of the event that hands a step's features from the kernels to the collective.  False (the
+    default, also ``HIGSFA_GATHER_LIGHT_EVENTS=0`` / unset): an ordinary event, whose record publishes the kernels' writes
+    to system scope — what any transport of the collective may rely on.  True: a device-scope event
+    (``hipEventDisableSystemFence``; a default event's record held the next launch up by 13 us on an MI355X, 3-4 us more
+    per step than this form) — enough when the collective reads the features with a kernel of THIS device, which is what
+    RCCL's all-gather does, but until a run on more than one GPU has confirmed it the caller must ask for it: ``bench.py``
+    does, after ``verify_against_blocking_gather`` has passed on every rank.  The two events in the other direction
+    ("the gather has finished READING buffer b": an order, no data) are always device-scope.
     """
 
-    def __init__(self, execute_local, n_cols, rows, device=None, collective=None):
+    def __init__(self, execute_local, n_cols, rows, device=None, collective=None, light_events=None):
         import torch
         import torch.distributed as dist
         self.torch = torch
@@ -78,19 +86,26 @@ class ShardedFlow(object):
             self.gathered = [torch.cuda.Event(), torch.cuda.Event()]     # for the caller (done_event): recorded on the side stream
             self._light = None
             if self.collective:
-                # device-scope events ordering the two streams against each other: [0/1] "gather of buffer b enqueued so far is
-                # done" (side stream -> kernels), [2] "kernels of this step are done" (kernels -> side stream)
+                # events ordering the two streams against each other: [0/1] "gather of buffer b enqueued so far is done"
+                # (side stream -> kernels; a read-before-overwrite order, device scope), [2] "kernels of this step are done"
+                # (kernels -> side stream; carries the features: scope chosen by light_events).  Created on self.device,
+                # whatever device is current in the calling thread.
                 import ctypes as C
+                import os
                 from . import _capi
+                if light_events is None:
+                    light_events = os.environ.get("HIGSFA_GATHER_LIGHT_EVENTS", "0") not in ("", "0")
+                self.light_events = bool(light_events)
                 self._capi, self._light = _capi, []
-                for _ in range(3):
+                dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+                for k in range(3):
                     h = C.c_void_p()
-                    _capi.check(_capi.lib().hg_event_create(C.byref(h)))
+                    _capi.check(_capi.lib().hg_event_create_on(C.byref(h), int(dev_index), 1 if (k < 2 or self.light_events) else 0))
                     self._light.append(h)
                 self._recorded = [False, False]
 
     @classmethod
-    def for_flow(cls, flow, n_cols, rows, device, collective=None):
+    def for_flow(cls, flow, n_cols, rows, device, collective=None, light_events=None):
         """Bind ``flow.execute_device`` (pyfaceanalysis_amd.flow.Flow on this rank's GPU)."""
         import numpy as np
         import torch
@@ -102,7 +117,7 @@ class ShardedFlow(object):
                 raise ValueError("ShardedFlow: x rows and the feature buffer must be contiguous")
             flow.execute_device(x_block.data_ptr(), np_dt[x_block.dtype], x_block.shape[0], x_block.stride(0),
                                 y_out.data_ptr(), np.float32, n_cols, n_cols, stream=stream)
-        return cls(run, n_cols, rows, device=device, collective=collective)
+        return cls(run, n_cols, rows, device=device, collective=collective, light_events=light_events)
 
     def step(self, x_local):
         """Enqueue one pass over this rank's block; returns the (world*rows, n_cols) gathered features
@@ -113,6 +128,13 @@ class ShardedFlow(object):
         m = int(x_local.shape[0])
         if m > self.rows:
             raise ValueError("rank %d: local block has %d rows, more than the %d allocated" % (self.rank, m, self.rows))
+        if self.cuda and torch.cuda.current_device() != self.device.index and self.device.index is not None:
+            with torch.cuda.device(self.device):      # events and streams of self.device: make it current for the calls below
+                return self._step(x_local, b, m)
+        return self._step(x_local, b, m)
+
+    def _step(self, x_local, b, m):
+        torch = self.torch
         if self.cuda and self.collective and self._recorded[b]:
             # The gather that read ys[b] two steps ago must be done before the kernels write ys[b] again.  It almost always
             # is, long ago: ask first (non-blocking) and spare the kernels' queue a barrier packet in front of its next
@@ -146,6 +168,34 @@ class ShardedFlow(object):
         else:
             gather_features(self.ys[b], self.y_alls[b])
         return self.y_alls[b]
+
+    def verify_against_blocking_gather(self, x_blocks, steps=6):
+        """Check the overlapped gather against an independent, fully synchronous one: ``steps`` steps over DIFFERENT input
+        blocks (``x_blocks[i % len(x_blocks)]``: consecutive steps give different features, so a peer block that arrives one
+        step stale, or that was read before its writes were visible, cannot pass), and after every step — once everything is
+        complete — a blocking all-gather of this rank's features straight from the buffer the kernels wrote.  Every rank
+        compares EVERY rank's block.  Returns True only if every step matched on every rank (a MIN all-reduce), so that
+        all ranks take the same decision.  Not for timed regions."""
+        import torch.distributed as dist
+        torch = self.torch
+        if not self.collective:
+            return True
+        ok = True
+        for i in range(int(steps)):
+            xb = x_blocks[i % len(x_blocks)]
+            y_over = self.step(xb)
+            b = (self._n - 1) & 1
+            self.wait()
+            ref = torch.zeros_like(y_over)
+            dist.all_gather_into_tensor(ref, self.ys[b])
+            if self.cuda:
+                torch.cuda.synchronize(self.device)
+            ok = ok and bool(torch.equal(ref, y_over))
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if self.cuda:
+            torch.cuda.synchronize(self.device)
+        return bool(int(flag.item()) == 1)
 
     def done_event(self, step_index=None):
         """The event recorded after the gather of step ``step_index`` (default: the last one enqueued); only the

@@ -280,27 +280,3 @@ def test_device_resident_strided_rows(native_lib, nets):
             else:
                 assert float(np.abs(got.astype(np.float64) - dense).max() / np.abs(dense).max()) <= 2e-6, (np_dt, pad)
     flow.close()
-
-
-def test_experimental_split_bf16_plan(native_lib, nets, monkeypatch):
-    """HIGSFA_BF16X3=1 (EXPERIMENT, never the default): layers 3..7 of U11L-128 with six bf16 products per fp32 product
-    (hg_fused_b3.hip).  It must stay inside the reference tolerance (1e-4 of max|ref|) and close to the exact-fp32 plan; it is
-    NOT bit-identical to it, nor across batch sizes (batches below 16 tiles take the fp32 kernels)."""
-    nodes = nets("U11L-128")
-    x = synth.make_subimages(1000, 128, dtype=np.uint8)
-    monkeypatch.setenv("HIGSFA_BF16X3", "1")
-    exp = Flow(nodes, output_dtype=np.float32)
-    assert exp.describe().count("EXPERIMENTAL HIGSFA_BF16X3") == 5
-    monkeypatch.delenv("HIGSFA_BF16X3")
-    std = Flow(nodes, output_dtype=np.float32)
-    assert "HIGSFA_BF16X3" not in std.describe()
-    a, b = exp.execute(x), std.execute(x)
-    ref = oracle.execute_flow(nodes, x[:64])
-    e_exp, e_std = rel_err(a[:64], ref), rel_err(b[:64], ref)
-    print("split-bf16 plan %.2e, fp32 plan %.2e against the float64 oracle; between them %.2e" % (e_exp, e_std, rel_err(a, b.astype(np.float64))))
-    assert e_exp <= TOL and e_exp <= 10 * max(e_std, 1e-6)
-    assert rel_err(a, b.astype(np.float64)) <= 2e-5
-    assert np.array_equal(exp.execute(x[:100]), std.execute(x[:100]))          # small batches: the same fp32 kernels
-    assert np.array_equal(exp.execute(x), a)                                   # deterministic
-    exp.close()
-    std.close()

@@ -53,7 +53,9 @@ def test_igsfa_variants_from_pickle(native_lib, tmp_path, seed):
     nodes = helpers.fuzz_igsfa_net(seed)
     mods, C = _fake_modules()
     path = _dump(tmp_path, nodes, mods, C)
-    _check(path, nodes, None, expect_fused=False, igsfa_lr_input=nodes[1].nodes[0].lr_input)
+    ig = nodes[1].nodes[0]
+    mo = dict(igsfa_matrix_orientation="n@R.T") if ig.scaling == "matrix" else {}      # the fake pickle stores R = scaling_matrix.T
+    _check(path, nodes, None, expect_fused=False, igsfa_lr_input=ig.lr_input, **mo)
 
 
 @pytest.mark.parametrize("reading", ["offset", "band"])

@@ -124,7 +124,13 @@ def test_igsfa_variants_roundtrip(tmp_path, seed):
     ig = nodes[1].nodes[0]
     mods, C = _fake_modules()
     path = _dump(tmp_path, nodes, mods, C)
-    got = pickle_import.load_flow_pickle(path, igsfa_lr_input=ig.lr_input)
+    mo = dict(igsfa_matrix_orientation="n@R.T") if ig.scaling == "matrix" else {}      # the fake pickle stores R = scaling_matrix.T
+    if ig.scaling == "matrix":      # R is square: its orientation must be stated, never assumed
+        with pytest.raises(ValueError, match="igsfa_matrix_orientation"):
+            pickle_import.load_flow_pickle(path, igsfa_lr_input=ig.lr_input)
+        with pytest.raises(ValueError, match="igsfa_matrix_orientation"):
+            pickle_import.load_flow_pickle(path, igsfa_lr_input=ig.lr_input, igsfa_matrix_orientation="R")
+    got = pickle_import.load_flow_pickle(path, igsfa_lr_input=ig.lr_input, **mo)
     assert got[1].nodes[0].scaling == ig.scaling and got[1].nodes[0].lr_input == ig.lr_input
     x = np.random.default_rng(0).normal(size=(7, nodes[0].input_dim))
     assert np.array_equal(oracle.execute_flow(got, x), oracle.execute_flow(nodes, x))
@@ -132,7 +138,10 @@ def test_igsfa_variants_roundtrip(tmp_path, seed):
     back = blob_to_flow(flow_to_blob(got))
     assert np.array_equal(oracle.execute_flow(back, x), oracle.execute_flow(nodes, x))
     if ig.lr_node is not None:       # the other reading gives different features: the field matters
-        other = pickle_import.load_flow_pickle(path, igsfa_lr_input="scaled" if ig.lr_input == "unscaled" else "unscaled")
+        other = pickle_import.load_flow_pickle(path, igsfa_lr_input="scaled" if ig.lr_input == "unscaled" else "unscaled", **mo)
+        assert not np.allclose(oracle.execute_flow(other, x), oracle.execute_flow(nodes, x))
+    if ig.scaling == "matrix":       # ... and so does the matrix orientation
+        other = pickle_import.load_flow_pickle(path, igsfa_lr_input=ig.lr_input, igsfa_matrix_orientation="n@R")
         assert not np.allclose(oracle.execute_flow(other, x), oracle.execute_flow(nodes, x))
 
 

@@ -44,6 +44,18 @@ for n in (37, 1, 64, 2):
         sf.wait()
         assert torch.equal(y2[:n], y)
     checked += 1
+# inputs that change from step to step (a block that arrives one step stale cannot pass): every step's WHOLE gathered matrix
+# against features computed independently for every rank's block, and the library's own check against a blocking gather
+n = 48
+lo, hi, per = shard_bounds(n, world, rank)
+sf = ShardedFlow(run, n_cols=K, rows=per)
+xs = [synth.make_subimages(n, 8, seed=50 + i, dtype=np.float64) for i in range(3)]
+refs = [mdp_restate.execute_flow(nodes, x)[:, :K].astype(np.float32) for x in xs]
+for i in range(7):
+    y = sf.step(torch.from_numpy(xs[i % 3][lo:hi]))
+    sf.wait()
+    assert np.abs(y[:n].numpy() - refs[i % 3]).max() <= 1e-6 * np.abs(refs[i % 3]).max(), (rank, i)
+assert sf.verify_against_blocking_gather([torch.from_numpy(x[lo:hi]) for x in xs], steps=5)
 dist.barrier()
 dist.destroy_process_group()
 with open(os.path.join({out!r}, "rank%d.ok" % rank), "w") as fh:

@@ -72,6 +72,31 @@ def test_collective_branch_matches_flow_execute(rccl_world1):
     flow.close()
 
 
+@pytest.mark.parametrize("light", [False, True])
+def test_hand_off_event_scopes_and_foreign_current_device(rccl_world1, light):
+    """Both scopes of the event that hands the features to the collective (ordinary = the default; device-scope = what
+    bench.py asks for after this same check has passed on every rank) reproduce a blocking all-gather on inputs that
+    change from step to step; the events belong to the ShardedFlow's device even when the calling thread's current device
+    is another one (with one GPU: the same one, reached through an explicit torch.cuda.device block)."""
+    import torch
+    from pyfaceanalysis_amd import synth
+    from pyfaceanalysis_amd.sharded import ShardedFlow
+    flow, nodes = _flow()
+    dev = torch.device("cuda", 0)
+    rows = 200
+    sf = ShardedFlow.for_flow(flow, K, rows, dev, collective=True, light_events=light)
+    assert sf.light_events is light
+    xs = [torch.from_numpy(synth.make_subimages(rows, 64, seed=300 + i, dtype=np.float32)).to(dev) for i in range(3)]
+    assert sf.verify_against_blocking_gather(xs, steps=9)
+    with torch.cuda.device(0):
+        y = sf.step(xs[1])
+    sf.wait()
+    want = flow.execute(xs[1].cpu().numpy().astype(np.float64))[:, :K].astype(np.float32)
+    assert np.array_equal(y.cpu().numpy(), want)
+    sf.close()
+    flow.close()
+
+
 def test_ragged_blocks_and_stale_rows(rccl_world1):
     """The last block of a ragged batch is short: rows beyond it are published as zeros even when a fuller step
     used the same buffer before (the buffers are reused); execute() slices to n_total."""
