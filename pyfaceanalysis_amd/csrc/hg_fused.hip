@@ -530,7 +530,7 @@ __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
                     }
                     if constexpr (REM) {
 #pragma unroll
-                        for (int t = 0; t < T; ++t) z[MT1 - 1][t] += rem4_rows(d4[t], g);
+                        for (int t = 0; t < T; ++t) add_rem4(z[MT1 - 1][t], d4[t]);
                     }
                     {   // next visit's blocks: next node of this group on the same tiles, or the group's first node on the next tiles
                         const bool in_group = ln + 1 < gn;
@@ -611,7 +611,7 @@ __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
                 }
                 if constexpr (REM) {
 #pragma unroll
-                    for (int t = 0; t < T; ++t) z[MT1 - 1][t] += rem4_rows(d4[t], g);
+                    for (int t = 0; t < T; ++t) add_rem4(z[MT1 - 1][t], d4[t]);
                 }
                 if (STAMP) ts1 = stamp_now();
                 node_tail<MT1, MT2, T, REM, FS>(P, wA2, b1 + MT1 * 16, g0 + ln, z, tile, lane);
@@ -736,7 +736,7 @@ __global__ void __launch_bounds__(256) k_stage_splitm(StageParams P, int mt1n, i
         }
         if (rem1) {
 #pragma unroll
-            for (int t = 0; t < T; ++t) z[t] += rem4_rows(d4[t], g);
+            for (int t = 0; t < T; ++t) add_rem4(z[t], d4[t]);
         }
         if (!P.has_exp) {
 #pragma unroll
@@ -794,7 +794,7 @@ __global__ void __launch_bounds__(256) k_stage_splitm(StageParams P, int mt1n, i
     }
     if (rem2) {
 #pragma unroll
-        for (int t = 0; t < T; ++t) y[t] += rem4_rows(d4[t], g);
+        for (int t = 0; t < T; ++t) add_rem4(y[t], d4[t]);
     }
     if (REM && P.pack_base > 0) {      // packed remainder tiles (StageParams::pack_base): full tiles as blocks, the remainder rows into the shared block
         if (rem2) {

@@ -186,22 +186,23 @@ __device__ __forceinline__ void gemm_block(WP wp, const f32x4 (&b)[T], f32x4 (&a
 // padding multiplications of those tiles gone.
 #define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 0, 0, 0)
 
-// Sum over the four lane groups (rows of 16 lanes) on the vector ALU: v_permlane16_swap pairs rows 0/1 and 2/3,
-// v_permlane32_swap the two halves — (r0 + r1) + (r2 + r3) in every row, the same association as the LDS-crossbar shuffles
-// (__shfl_xor 16, then 32) this replaces, without their ~100-cycle round trips.
-__device__ __forceinline__ float sum_lane_groups(float v) {
-    const auto p = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+// The four k partial sums of a 4x4-form tile sit in the four lane groups (rows of 16 lanes), one register per remainder row; lane
+// group g wants the total of register g.  A reduce-scatter on the vector ALU in three swaps and three adds (round 4; it was a
+// full sum of every register in every row — eight swaps, eight adds and a select chain): v_permlane16_swap with d0 / d1
+// exchanges the odd rows of one with the even rows of the other, so one add leaves (row 0 + row 1) of d0 in the even rows and of
+// d1 in the odd rows; the same for d2 / d3; v_permlane32_swap of the two results exchanges the halves, and the last add leaves
+// the total of d_g in row g.  Every total is (r0 + r1) + (r2 + r3) with the operands in the old order: the same bits.
+__device__ __forceinline__ float rem4_total(f32x4 d) {
+    const auto p = __builtin_amdgcn_permlane16_swap(__float_as_uint(d[0]), __float_as_uint(d[1]), false, false);
     const float t = __uint_as_float(p[0]) + __uint_as_float(p[1]);
-    const auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(t), __float_as_uint(t), false, false);
-    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+    const auto q = __builtin_amdgcn_permlane16_swap(__float_as_uint(d[2]), __float_as_uint(d[3]), false, false);
+    const float u = __uint_as_float(q[0]) + __uint_as_float(q[1]);
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(t), __float_as_uint(u), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-__device__ __forceinline__ f32x4 rem4_rows(f32x4 d, int g) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) d[i] = sum_lane_groups(d[i]);
-    const float v = g == 0 ? d[0] : g == 1 ? d[1] : g == 2 ? d[2] : d[3];
-    return f32x4{v, 0.f, 0.f, 0.f};
-}
+// acc (a remainder tile's accumulator: row g of the tile = register 0 of lane group g) += the 4x4-form partial sums d
+__device__ __forceinline__ void add_rem4(f32x4& acc, f32x4 d) { acc[0] += rem4_total(d); }
 
 // gemm_block with the last m-tile in 4x4 form: tiles 0 .. MT-2 accumulate in acc, the last one in d4.
 template <int MT, int T, typename WP>
@@ -287,7 +288,7 @@ __device__ __forceinline__ void node_tail(const StageParams& P, WP wA2, BP b2, i
     }
     if constexpr (REM) {
 #pragma unroll
-        for (int t = 0; t < T; ++t) y[MT2 - 1][t] += rem4_rows(d4[t], g);
+        for (int t = 0; t < T; ++t) add_rem4(y[MT2 - 1][t], d4[t]);
         if (P.pack_base > 0) {      // full tiles as blocks; the remainder rows into this node's register of the shared block
 #pragma unroll
             for (int mt = 0; mt < MT2 - 1; ++mt)

@@ -495,7 +495,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(TT == 
             if constexpr (REM4) {
 #pragma unroll
                 for (int t = 0; t < T; ++t) {
-                    z1[1][t] += rem4_rows(d4[t], g);
+                    add_rem4(z1[1][t], d4[t]);
                     d4[t] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             }
@@ -537,7 +537,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(TT == 
             }
             if constexpr (REM4) {
 #pragma unroll
-                for (int t = 0; t < T; ++t) y1[1][t] += rem4_rows(d4[t], g);
+                for (int t = 0; t < T; ++t) add_rem4(y1[1][t], d4[t]);
             }
             if (REM4 && Q.pack_base > 0) {     // packed remainder tiles (hg_fused_dev.hpp, StageParams::pack_base): stored one iteration later
 #pragma unroll
@@ -803,7 +803,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
                 z1[0] = MFMA16(q_a1[kb][0][r], y0[kb][r], z1[0]);
                 d4 = MFMA4(q_a1[kb][1][r], y0[kb][r], d4);
             }
-        z1[1] += rem4_rows(d4, g);
+        add_rem4(z1[1], d4);
         d4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int fi = 0; fi < 2; ++fi) {
@@ -820,7 +820,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
             y1[0] = MFMA16(q_a2t[fi][0], e0, y1[0]);
             d4 = MFMA4(q_a2t[fi][1], e0, d4);
         }
-        y1[1] += rem4_rows(d4, g);
+        add_rem4(y1[1], d4);
         st_y0 = y1[0];
         st_y1 = y1[1][0];
         st_tile = tile;
