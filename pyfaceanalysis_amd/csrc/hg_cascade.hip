@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstring>
 
 #include "hg_common.hpp"
 
@@ -186,7 +188,40 @@ __device__ __forceinline__ bool update_one(int type, const hg_cascade_consts& c,
     }
 }
 
-__global__ void __launch_bounds__(1024) k_cascade_stage(int type, hg_cascade_consts c, StageArrays A, int32_t* host_count) {
+// What the host polls instead of synchronising the stream (pinned, device-visible): word 0 = survivor count, word 1 = sequence
+// number of the stage that wrote it (written last, system scope).  A stream synchronisation costs the caller 20-40 us before it
+// has caught up with the device again; a poll sees the word 2-3 us after the store.
+__device__ __forceinline__ void publish_count(int32_t* host_count, int cnt, int seq) {
+    host_count[0] = cnt;
+    __threadfence_system();
+    __hip_atomic_store(host_count + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// The final survivors for the host, written by the last stage's kernel into pinned memory (a handful of rows): the call ends with
+// a poll of the count word instead of four device-to-host copies and a stream synchronisation.
+struct HostResults {
+    double* coords;      // [cap][4]
+    double* angles;      // [cap]
+    double* conf;        // [cap]
+    int32_t* oidx;       // [cap]
+    int32_t cap;
+};
+
+// Start of a frame: candidate i = original window i (the host copied the boxes into orig_coords); replaces five small copies /
+// memsets and the synchronisation that kept their host temporaries alive.
+__global__ void k_cascade_init(int n, const double* __restrict__ orig_coords, double* __restrict__ coords, double* __restrict__ angles,
+                               double* __restrict__ neg, double* __restrict__ conf, int32_t* __restrict__ oidx, int32_t* __restrict__ count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *count = n;
+    if (i >= n) return;
+    for (int q = 0; q < 4; ++q) coords[(size_t)i * 4 + q] = orig_coords[(size_t)i * 4 + q];
+    angles[i] = 0.0;
+    neg[i] = 0.0;
+    conf[i] = 0.0;
+    oidx[i] = i;
+}
+
+__global__ void __launch_bounds__(1024) k_cascade_stage(int type, hg_cascade_consts c, StageArrays A, int32_t* host_count, int seq, HostResults H) {
     __shared__ int wsum[16];
     __shared__ int base;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -236,9 +271,105 @@ __global__ void __launch_bounds__(1024) k_cascade_stage(int type, hg_cascade_con
         const int j = e / kf, f = e - j * kf;
         A.sl[nxt][(size_t)j * kf + f] = A.sl[cur][(size_t)A.map[j] * kf + f];
     }
+    if (H.cap > 0 && cnt <= H.cap) {      // last stage: the survivors themselves, for the host (nxt[] is complete: barrier)
+        __syncthreads();
+        for (int j = tid; j < cnt; j += blockDim.x) {
+            for (int q = 0; q < 4; ++q) H.coords[(size_t)j * 4 + q] = A.coords[nxt][(size_t)j * 4 + q];
+            H.angles[j] = A.angles[nxt][j];
+            H.conf[j] = A.conf[nxt][j];
+            H.oidx[j] = A.oidx[nxt][j];
+        }
+        __threadfence_system();
+        __syncthreads();
+    }
     if (tid == 0) {
         *A.count_out = cnt;
-        if (host_count) *host_count = cnt;
+        if (host_count) publish_count(host_count, cnt, seq);
+    }
+}
+
+// The same stage for batches of many frames' windows (the single workgroup above walks 1024 candidates per step): two launches
+// of one workgroup per kChunk candidates.  `mark` updates every candidate IN PLACE in the cur arrays (nobody else reads them any
+// more), writes its keep flag and the chunk's survivor count; `scatter` turns the chunk counts into its base offset (a sum over
+// the chunks before it), repeats the chunk-local scan on the flags and moves the survivors, order preserved, into the nxt arrays.
+constexpr int kChunk = 4096;
+
+__global__ void __launch_bounds__(1024) k_cascade_stage_mark(int type, hg_cascade_consts c, StageArrays A, int32_t* __restrict__ chunk_count) {
+    __shared__ int wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = min(*A.count_in, A.n_max), cur = A.cur;
+    const int lo = blockIdx.x * kChunk, hi = min(n, lo + kChunk);
+    int kept = 0;
+    for (int i = lo + tid; i < hi; i += blockDim.x) {
+        double x0 = A.coords[cur][(size_t)i * 4], y0 = A.coords[cur][(size_t)i * 4 + 1], x1 = A.coords[cur][(size_t)i * 4 + 2], y1 = A.coords[cur][(size_t)i * 4 + 3];
+        double ang = A.angles[cur][i];
+        const int32_t oi = A.oidx[cur][i];
+        const bool wrong = update_one(type, c, x0, y0, x1, y1, ang, A.reg[i], A.orig_coords + (size_t)oi * 4, A.orig_angles[oi], A.orig_level + (size_t)oi * 3);
+        A.coords[cur][(size_t)i * 4] = x0; A.coords[cur][(size_t)i * 4 + 1] = y0; A.coords[cur][(size_t)i * 4 + 2] = x1; A.coords[cur][(size_t)i * 4 + 3] = y1;
+        A.angles[cur][i] = ang;
+        A.discard[i] = wrong ? 1 : 0;
+        kept += wrong ? 0 : 1;
+    }
+    for (int o = 32; o > 0; o >>= 1) kept += __shfl_xor(kept, o);
+    if (lane == 0) wsum[wave] = kept;
+    __syncthreads();
+    if (tid == 0) {
+        int t = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += wsum[w];
+        chunk_count[blockIdx.x] = t;
+    }
+}
+
+__global__ void __launch_bounds__(1024) k_cascade_stage_scatter(int type, StageArrays A, const int32_t* __restrict__ chunk_count, int32_t* host_count, int seq) {
+    __shared__ int wsum[16];
+    __shared__ int base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = min(*A.count_in, A.n_max), cur = A.cur, nxt = 1 - cur;
+    const int lo = blockIdx.x * kChunk, hi = min(n, lo + kChunk);
+    // base = survivors of the chunks before this one (the last workgroup also learns the total)
+    int part = 0;
+    for (int b = tid; b < (int)blockIdx.x; b += blockDim.x) part += chunk_count[b];
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    if (lane == 0) wsum[wave] = part;
+    __syncthreads();
+    if (tid == 0) {
+        int t = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += wsum[w];
+        base = t;
+    }
+    __syncthreads();
+    const int kf = A.k_feat;
+    for (int i0 = lo; i0 < hi; i0 += blockDim.x) {
+        const int i = i0 + tid;
+        const int keep = (i < hi && A.discard[i] == 0) ? 1 : 0;
+        const unsigned long long m = __ballot(keep);
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+        if (keep) {
+            const int j = off + before;
+            const double ang = A.angles[cur][i];
+            A.map[j] = i;
+            for (int q = 0; q < 4; ++q) A.coords[nxt][(size_t)j * 4 + q] = A.coords[cur][(size_t)i * 4 + q];
+            A.angles[nxt][j] = ang;
+            A.neg_angles[j] = -ang;
+            A.oidx[nxt][j] = A.oidx[cur][i];
+            A.conf[nxt][j] = type == HG_STAGE_DISC ? A.reg[i] : A.conf[cur][i];
+            for (int f = 0; f < kf; ++f) A.sl[nxt][(size_t)j * kf + f] = A.sl[cur][(size_t)i * kf + f];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int t = 0;
+            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += wsum[w];
+            base += t;
+        }
+        __syncthreads();
+    }
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) {      // the last chunk's end offset is the total
+        *A.count_out = base;
+        if (host_count) publish_count(host_count, base, seq);
     }
 }
 
@@ -306,8 +437,11 @@ struct hg_cascade {
     double cut_offs[10];
     hg_patcher* patcher = nullptr;
     int64_t cap = 0;
-    hg::DevBuf coords[2], angles[2], conf[2], oidx[2], sl[2], subs[2], neg, reg, discard, map, count, orig_coords, orig_level, orig_angles;
-    int32_t* host_count = nullptr;       // pinned, device-visible
+    hg::DevBuf coords[2], angles[2], conf[2], oidx[2], sl[2], subs[2], neg, reg, discard, map, count, orig_coords, orig_level, orig_angles, chunk_count;
+    int32_t* host_count = nullptr;       // pinned, device-visible: {count, sequence number} (publish_count)
+    int32_t seq = 0;                     // sequence number of the last read-back asked for
+    char* host_res = nullptr;            // pinned: the final survivors (HostResults), kResCap rows
+    static constexpr int kResCap = 4096;
 
     void reserve(int64_t n0) {
         if (n0 <= cap) return;
@@ -358,6 +492,8 @@ int hg_cascade_create(const hg_cascade_stage* stages, int n_stages, int sub_w, i
         for (int i = 0; i < 10; ++i) c->cut_offs[i] = i < n_cut_offs ? cut_offs_face[i] : 0.0;
         if (hg_patcher_create(device, &c->patcher) != HG_OK) hg::fail(HG_ERR_DEVICE, "%s", hg_last_error());
         HG_HIP(hipHostMalloc((void**)&c->host_count, 64, hipHostMallocDefault));
+        c->host_count[0] = c->host_count[1] = 0;
+        HG_HIP(hipHostMalloc((void**)&c->host_res, (size_t)hg_cascade::kResCap * 52, hipHostMallocDefault));
         *out = c.release();
     });
 }
@@ -367,6 +503,7 @@ void hg_cascade_free(hg_cascade* c) {
     if (hipSetDevice(c->device) == hipSuccess) {
         if (c->patcher) hg_patcher_free(c->patcher);
         if (c->host_count) (void)hipHostFree(c->host_count);
+        if (c->host_res) (void)hipHostFree(c->host_res);
     }
     delete c;
 }
@@ -391,18 +528,29 @@ int hg_cascade_detect_device(hg_cascade* c, const void* frame_dev, int frame_h, 
         c->reserve(n0);
         HG_HIP(hipMemcpyAsync(c->orig_coords.p, boxes_host, (size_t)n0 * 32, hipMemcpyHostToDevice, st));
         HG_HIP(hipMemcpyAsync(c->orig_level.p, level_host, (size_t)n0 * 24, hipMemcpyHostToDevice, st));
-        HG_HIP(hipMemcpyAsync(c->coords[0].p, c->orig_coords.p, (size_t)n0 * 32, hipMemcpyDeviceToDevice, st));
-        HG_HIP(hipMemsetAsync(c->angles[0].p, 0, (size_t)n0 * 8, st));
-        HG_HIP(hipMemsetAsync(c->neg.p, 0, (size_t)n0 * 8, st));
-        HG_HIP(hipMemsetAsync(c->conf[0].p, 0, (size_t)n0 * 8, st));
-        {   // orig_index = 0 .. n0-1, count = n0
-            std::vector<int32_t> idx((size_t)n0);
-            for (int64_t i = 0; i < n0; ++i) idx[i] = (int32_t)i;
-            HG_HIP(hipMemcpyAsync(c->oidx[0].p, idx.data(), (size_t)n0 * 4, hipMemcpyHostToDevice, st));
-            const int32_t cnt0 = (int32_t)n0;
-            HG_HIP(hipMemcpyAsync(c->count.p, &cnt0, 4, hipMemcpyHostToDevice, st));
-            HG_HIP(hipStreamSynchronize(st));          // idx / cnt0 are stack / heap temporaries
-        }
+        hipLaunchKernelGGL(k_cascade_init, (unsigned)((n0 + 255) / 256), 256, 0, st, (int)n0, (const double*)c->orig_coords.p, (double*)c->coords[0].p,
+                           (double*)c->angles[0].p, (double*)c->neg.p, (double*)c->conf[0].p, (int32_t*)c->oidx[0].p, (int32_t*)c->count.p);
+        HG_HIP(hipGetLastError());
+        // the count word is polled, never waited for with a stream synchronisation (publish_count); a deadline guards against a
+        // device that never answers
+        auto poll_count = [&](int32_t seq) -> int64_t {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (unsigned spins = 0;; ++spins) {
+                if (__atomic_load_n(c->host_count + 1, __ATOMIC_ACQUIRE) == seq) return c->host_count[0];
+                if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
+                    HG_HIP(hipStreamSynchronize(st));
+                    if (__atomic_load_n(c->host_count + 1, __ATOMIC_ACQUIRE) == seq) return c->host_count[0];
+                    hg::fail(HG_ERR_DEVICE, "cascade stage did not report its survivor count");
+                }
+                __builtin_ia32_pause();
+            }
+        };
+        HostResults H{};
+        H.coords = (double*)c->host_res;
+        H.angles = (double*)(c->host_res + (size_t)hg_cascade::kResCap * 32);
+        H.conf = (double*)(c->host_res + (size_t)hg_cascade::kResCap * 40);
+        H.oidx = (int32_t*)(c->host_res + (size_t)hg_cascade::kResCap * 48);
+        bool results_on_host = false;
         int cur = 0, cnt_slot = 0;
         int sb = 0;                                    // which of subs[] holds the extracted sub-images, row-aligned with the candidates
         int64_t n_bound = n0, rows = 0;                // n_bound: host-side upper bound of the candidate count (exact after a Disc stage)
@@ -461,11 +609,25 @@ int hg_cascade_detect_device(hg_cascade* c, const void* frame_dev, int frame_h, 
             A.k_feat = c->k;
             A.cur = cur;
             A.n_max = (int32_t)n_bound;
-            // the host needs the exact count only where it shrinks a lot and sizes expensive launches: after a Disc stage — and only
-            // while there is something to save: a flow call on <= 128 rows sits at its latency floor (63-88 us),
-            // less than what the read-back and the host's catching up with the device cost (~30-50 us)
-            const bool want_count = (S.type == HG_STAGE_DISC && n_bound > 128) || k + 1 == ns;
-            hipLaunchKernelGGL(k_cascade_stage, 1, 1024, 0, st, S.type, cc, A, want_count ? c->host_count : nullptr);
+            // the host needs the exact count where it shrinks and sizes the next launches: after every Disc stage (the read-back is a
+            // poll of a pinned word now, cheap enough for the small stages too), and at the end
+            const bool last = k + 1 == ns;
+            const bool want_count = S.type == HG_STAGE_DISC || last;
+            const int32_t seq = want_count ? ++c->seq : 0;
+            HostResults Hk{};
+            if (n_bound > 2 * kChunk) {      // many frames' windows: one workgroup per kChunk candidates, two launches
+                const unsigned chunks = (unsigned)((n_bound + kChunk - 1) / kChunk);
+                c->chunk_count.alloc((size_t)chunks * 4);
+                hipLaunchKernelGGL(k_cascade_stage_mark, chunks, 1024, 0, st, S.type, cc, A, (int32_t*)c->chunk_count.p);
+                hipLaunchKernelGGL(k_cascade_stage_scatter, chunks, 1024, 0, st, S.type, A, (const int32_t*)c->chunk_count.p, want_count ? c->host_count : nullptr, seq);
+            } else {
+                if (last && n_bound <= hg_cascade::kResCap) {
+                    Hk = H;
+                    Hk.cap = hg_cascade::kResCap;
+                    results_on_host = true;
+                }
+                hipLaunchKernelGGL(k_cascade_stage, 1, 1024, 0, st, S.type, cc, A, want_count ? c->host_count : nullptr, seq, Hk);
+            }
             if (carry[(size_t)k]) {       // this stage's compaction applied to the sub-images as well (:753)
                 const int vec16 = row % 16 == 0 ? 1 : 0;
                 hipLaunchKernelGGL(k_gather_rows, (unsigned)std::min<int64_t>(n_bound, 16384), 256, 0, st, (const char*)c->subs[sb].p, (char*)c->subs[1 - sb].p,
@@ -475,14 +637,16 @@ int hg_cascade_detect_device(hg_cascade* c, const void* frame_dev, int frame_h, 
             HG_HIP(hipGetLastError());
             cur = 1 - cur;
             cnt_slot = 1 - cnt_slot;
-            if (want_count) {
-                HG_HIP(hipStreamSynchronize(st));
-                n_bound = *c->host_count;
-            }
-            if (stage_counts) stage_counts[k] = want_count ? (int32_t)n_bound : -1;      // -1: not read back (no Disc stage)
+            if (want_count) n_bound = poll_count(seq);
+            if (stage_counts) stage_counts[k] = want_count ? (int32_t)n_bound : -1;      // -1: not read back (the stage cannot discard by a cut-off: bound of the last Disc stage)
         }
         if (n_bound > out_cap) hg::fail(HG_ERR_ARG, "%lld detections but room for %lld", (long long)n_bound, (long long)out_cap);
-        if (n_bound > 0) {
+        if (n_bound > 0 && results_on_host) {      // written by the last stage's kernel before it published the count
+            if (out_coords) memcpy(out_coords, H.coords, (size_t)n_bound * 32);
+            if (out_angles) memcpy(out_angles, H.angles, (size_t)n_bound * 8);
+            if (out_orig_index) memcpy(out_orig_index, H.oidx, (size_t)n_bound * 4);
+            if (out_confidence) memcpy(out_confidence, H.conf, (size_t)n_bound * 8);
+        } else if (n_bound > 0) {
             if (out_coords) HG_HIP(hipMemcpyAsync(out_coords, c->coords[cur].p, (size_t)n_bound * 32, hipMemcpyDeviceToHost, st));
             if (out_angles) HG_HIP(hipMemcpyAsync(out_angles, c->angles[cur].p, (size_t)n_bound * 8, hipMemcpyDeviceToHost, st));
             if (out_orig_index) HG_HIP(hipMemcpyAsync(out_orig_index, c->oidx[cur].p, (size_t)n_bound * 4, hipMemcpyDeviceToHost, st));

@@ -81,6 +81,74 @@ k_gauss_regression(const T* __restrict__ x, int64_t ldx, int64_t n, int K, int d
     }
 }
 
+// The same regression with the quadratic forms spread over a workgroup (round 4).  Above, lane c walks the d x d matrix of its
+// class alone — 400 dependent steps for the pose regressors (50 classes, 20 features), with every lane of a load on another
+// cache line: 25-32 us for a call on a handful of rows, nine times per frame.  Here thread (c, i) of four waves computes
+// t_i = sum_j S_c[i][j] (x_j - m_c[j]) from one contiguous matrix row and leaves it in LDS; wave 0 then forms
+// q += t_i (x_i - m_c[i]) over a class's d rows in the order — and with the very expression — of the loop above and finishes
+// exactly as above: the same operations in the same order on every value, hence the same bits (tested).  For K d <= 4096
+// (32 KiB of LDS).
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_gauss_regression_wg(const T* __restrict__ x, int64_t ldx, int64_t n, int K, int d, const double* __restrict__ means,
+                      const double* __restrict__ inv_covs, const double* __restrict__ logw, const double* __restrict__ avg,
+                      double* __restrict__ out_reg, double* __restrict__ out_std) {
+    extern __shared__ double lds_g[];
+    double* xs = lds_g;              // [64]
+    double* term = lds_g + 64;       // [K * d]
+    const int64_t row = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid < d) xs[tid] = (double)x[row * ldx + tid];
+    __syncthreads();
+    for (int e = tid; e < K * d; e += blockDim.x) {
+        const int c = e / d, i = e - c * d;
+        const double* m = means + (size_t)c * d;
+        const double* S = inv_covs + (size_t)c * d * d + (size_t)i * d;
+        double t = 0;
+        for (int j = 0; j < d; ++j) t += S[j] * (xs[j] - m[j]);
+        term[e] = t;
+    }
+    __syncthreads();
+    if (tid >= 64) return;
+    double lmax = -INFINITY;
+    double lp[kMaxClasses / 64];
+#pragma unroll
+    for (int s = 0; s < kMaxClasses / 64; ++s) {
+        const int c = lane + 64 * s;
+        double v = -INFINITY;
+        if (c < K) {
+            const double* m = means + (size_t)c * d;
+            double q = 0;
+            for (int i = 0; i < d; ++i) q += term[c * d + i] * (xs[i] - m[i]);      // the expression of the kernel above, term = its t
+            v = logw[c] - 0.5 * q;
+        }
+        lp[s] = v;
+        lmax = fmax(lmax, v);
+    }
+    for (int o = 32; o > 0; o >>= 1) lmax = fmax(lmax, __shfl_xor(lmax, o));
+    double sw = 0, swa = 0, swa2 = 0;
+#pragma unroll
+    for (int s = 0; s < kMaxClasses / 64; ++s) {
+        const int c = lane + 64 * s;
+        if (c < K) {
+            const double w = exp(lp[s] - lmax), a = avg[c];
+            sw += w;
+            swa += w * a;
+            swa2 += w * a * a;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        sw += __shfl_xor(sw, o);
+        swa += __shfl_xor(swa, o);
+        swa2 += __shfl_xor(swa2, o);
+    }
+    if (lane == 0) {
+        const double reg = swa / sw;
+        out_reg[row] = reg;
+        if (out_std) out_std[row] = sqrt(fmax(swa2 / sw - reg * reg, 0.0));
+    }
+}
+
 template <typename F>
 int guarded(F&& fn) {
     try {
@@ -98,6 +166,19 @@ int guarded(F&& fn) {
 void launch(hg_gauss* g, const void* x, int x_dtype, int64_t n, int64_t ldx, double* reg, double* sd, hipStream_t st) {
     if (n == 0) return;
     if (n > 0x7fffffffll) hg::fail(HG_ERR_ARG, "too many rows");
+    if (x_dtype != HG_F32 && x_dtype != HG_F64) hg::fail(HG_ERR_ARG, "feature dtype must be HG_F32 or HG_F64");
+    const bool no_wg = getenv("HIGSFA_GAUSS_WAVE") != nullptr;      // tests: the one-wave-per-row kernel only (read per call)
+    if ((int64_t)g->K * g->d <= 4096 && !no_wg) {
+        const size_t lds = (size_t)(64 + g->K * g->d) * 8;
+        if (x_dtype == HG_F32)
+            hipLaunchKernelGGL(k_gauss_regression_wg<float>, (unsigned)n, 256, lds, st, (const float*)x, ldx, n, g->K, g->d, (const double*)g->means.p,
+                               (const double*)g->inv_covs.p, (const double*)g->logw.p, (const double*)g->avg.p, reg, sd);
+        else
+            hipLaunchKernelGGL(k_gauss_regression_wg<double>, (unsigned)n, 256, lds, st, (const double*)x, ldx, n, g->K, g->d, (const double*)g->means.p,
+                               (const double*)g->inv_covs.p, (const double*)g->logw.p, (const double*)g->avg.p, reg, sd);
+        HG_HIP(hipGetLastError());
+        return;
+    }
     if (x_dtype == HG_F32)
         hipLaunchKernelGGL(k_gauss_regression<float>, (unsigned)n, 64, 0, st, (const float*)x, ldx, n, g->K, g->d,
                            (const double*)g->means.p, (const double*)g->inv_covs.p, (const double*)g->logw.p,

@@ -122,10 +122,10 @@ def test_device_cascade_matches_restated_loop(native_lib, nets, sequence):
         return dev_reg              # the loop is fed the device value so that coordinates can be compared bit for bit
     ref = CR.run_cascade([s.name for s in stages], [s.flow is not None for s in stages], boxes, level, pipe, extract, execute, regress)
     assert [k for k, _ in checked] == list(range(len(stages))) and all(n > 0 for _, n in checked)     # every stage, on real rows
-    # survivor counts are read back after Disc stages only (-1 elsewhere: the count stays on the device)
-    # (and only while more than 128 candidates are left: below that the read-back costs more than it saves)
+    # survivor counts are read back (a poll of a pinned word) after every Disc stage and at the end (-1 elsewhere: the count stays
+    # on the device)
     known = [i for i, c in enumerate(got["counts"]) if c >= 0 and stages[i].type == "Disc"]
-    assert 1 <= len(known) <= sum(s.type == "Disc" for s in stages) and known[0] == 0
+    assert len(known) == sum(s.type == "Disc" for s in stages) and known[0] == 0
     assert [got["counts"][i] for i in known] == [ref["counts"][i] for i in known], (got["counts"], ref["counts"])
     assert got["rows_executed"] >= ref["rows_executed"]        # launches between two Disc stages are sized by the last count read
     assert 0 < got["counts"][-1] < len(boxes) and got["counts"][0] < len(boxes)
@@ -134,6 +134,18 @@ def test_device_cascade_matches_restated_loop(native_lib, nets, sequence):
     assert np.allclose(got["confidence"], ref["confidence"], rtol=1e-12, atol=1e-12)
     if any(s.type == "PAng" for s in stages[:-1]):
         assert np.abs(got["angles"]).max() > 0       # rotated extraction really took part
+    # several frames' worth of windows in ONE batch (the glue kernel was one workgroup): the frame's windows repeated
+    # until there are more than 20 000 — first stages on the multi-workgroup glue (mark + scatter), later ones on the single
+    # workgroup — must give the single batch's survivors once per copy, in order, bit for bit
+    copies = -(-20500 // len(boxes))
+    big = dc.detect(torch.from_numpy(frame).cuda(), smallest_face=0.3, windows=(np.tile(boxes, (copies, 1)), np.tile(level, (copies, 1))))
+    assert big["n_windows"] == copies * len(boxes) > 20000
+    n1 = len(got["orig_index"])
+    assert len(big["orig_index"]) == copies * n1
+    assert np.array_equal(big["orig_index"], (np.arange(copies)[:, None] * len(boxes) + got["orig_index"][None, :]).reshape(-1))
+    assert np.array_equal(big["coords"], np.tile(got["coords"], (copies, 1))) and np.array_equal(big["angles"], np.tile(got["angles"], copies))
+    assert np.array_equal(big["confidence"], np.tile(got["confidence"], copies))
+    assert [c for c in big["counts"] if c >= 0] == [copies * c for c in got["counts"] if c >= 0]
     # the pieces the loop was fed: windows vs PIL's rule, features vs the oracle
     assert np.array_equal(subs0[::7], pil_restate.extract_subimages_rotate(frame, boxes[::7], np.zeros(len(boxes[::7])), (16, 16)))
     r = mdp_restate.execute_flow(nodes, subs0[::5])

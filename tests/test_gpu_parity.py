@@ -334,4 +334,23 @@ def test_gaussian_regression(native_lib):
                                        clf.p, clf.avg_labels, want_std=False)
         assert np.allclose(reg32, ref32, rtol=1e-9, atol=1e-9 * np.abs(ref32).max())
         assert clf.regression(x[:0]).shape == (0,)
+        # the one-wave-per-row kernel (classifiers too large for the workgroup form's LDS) gives the same bits
+        os.environ["HIGSFA_GAUSS_WAVE"] = "1"
+        try:
+            reg_w, std_w = clf.regression(x, estimate_std=True)
+        finally:
+            del os.environ["HIGSFA_GAUSS_WAVE"]
+        assert np.array_equal(reg_w, reg) and np.array_equal(std_w, std)
         clf.close()
+    # a classifier beyond the workgroup form (K d > 4096): 300 classes x 20 features, against the C restatement
+    rng = np.random.default_rng(5)
+    K, d = 300, 20
+    means = rng.normal(size=(K, d)) * 3
+    A = rng.normal(size=(K, d, d))
+    inv_covs = A @ A.transpose(0, 2, 1) / d + np.eye(d) * 0.5
+    sqrt_def = np.array([np.sqrt(np.linalg.det(np.linalg.inv(ic))) for ic in inv_covs])
+    clf = GaussianClassifier(means, inv_covs, sqrt_def, np.full(K, 1.0 / K), avg_labels=rng.normal(size=K))
+    x = means[rng.integers(0, K, 40)] + rng.normal(size=(40, d)) * 0.3
+    want = ref_c.gauss_regression(x, clf.means, clf.inv_covs, clf._sqrt_def_covs, clf.p, clf.avg_labels, want_std=False)
+    assert np.allclose(clf.regression(x), want, rtol=1e-9, atol=1e-9 * np.abs(want).max())
+    clf.close()
