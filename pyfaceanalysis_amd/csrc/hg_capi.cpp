@@ -89,16 +89,24 @@ struct Replica {
     void create(int dev) {
         HG_HIP(hipSetDevice(dev));
         exec->to_device();
+        need_streams();
+        HG_HIP(hipDeviceSynchronize());
+        int lb = 0;
+        large_bar = hipDeviceGetAttribute(&lb, hipDeviceAttributeIsLargeBar, dev) == hipSuccess && lb != 0;
+        device = dev;
+    }
+    // Streams and events of the host path.  Created with the replica, not on first use: which hardware queue a later stream of
+    // the process lands on depends on how many exist already, and with these three in place the side stream of the sharded step
+    // (sharded.py) shares its queue with the kernels' stream — a hand-off inside one queue costs 12-17 us per step, across two
+    // queues 35 (profiles/r04_rccl_world1.txt: measured both ways).
+    void need_streams() {
+        if (compute) return;
         HG_HIP(hipStreamCreateWithFlags(&compute, hipStreamNonBlocking));
         for (int c = 0; c < NC; ++c) HG_HIP(hipStreamCreateWithFlags(&copy[c], hipStreamNonBlocking));
         for (int b = 0; b < NB; ++b) {
             for (int c = 0; c < NC; ++c) HG_HIP(hipEventCreateWithFlags(&ev_h2d[b][c], hipEventDisableTiming));
             HG_HIP(hipEventCreateWithFlags(&ev_out[b], hipEventDisableTiming));
         }
-        HG_HIP(hipDeviceSynchronize());
-        int lb = 0;
-        large_bar = hipDeviceGetAttribute(&lb, hipDeviceAttributeIsLargeBar, dev) == hipSuccess && lb != 0;
-        device = dev;
     }
     void need_pinned(size_t ring_b, size_t yb) {
         if (ring_b > ring_bytes) {
@@ -401,6 +409,7 @@ void run_host_rows_impl(hg_flow* f, Replica& rep, const void* x, int x_dtype, in
     // the DMA engine ran at 25 - 45 GB/s beside the packers' memory traffic and trailed them by up to 0.4 ms at the end of a call.
     const bool direct = rep.large_bar && f->direct;
     const size_t ring_want = direct ? 0 : std::max<size_t>(64 * row_given, std::min<size_t>((size_t)64 << 20, (size_t)n * row_given));
+    rep.need_streams();
     rep.need_pinned(ring_want, (size_t)widest_pass * y_cols * ys);
     for (int b = 0; b < NB; ++b) {
         rep.dx[b].alloc(std::min<size_t>(pass_bytes, (size_t)((n + 15) / 16 * 16) * row_given));

@@ -32,6 +32,20 @@ def gather_features(y_local, y_all):
     return y_all
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(torch, device):
+    """ONE side stream per device and process, shared by every ShardedFlow on it.  Streams compete for the device's few
+    hardware queues and which queue a new stream lands on depends on how many were created before it: measured at world size
+    1 (profiles/r04_rccl_world1.txt), the step costs 0.522 ms with the process's first side stream, 0.544 with its second,
+    and 0.908 with the fourth high-priority one, against 0.508 collective-free — so the choice is made once."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device)
+    return _SIDE_STREAMS[key]
+
+
 class ShardedFlow(object):
     """One rank's share of a sharded ``flow.execute``.
 
@@ -82,7 +96,7 @@ class ShardedFlow(object):
         self._filled = [0, 0]          # rows of ys[b] that may hold features of an earlier step
         if self.cuda:
             self.stream = torch.cuda.current_stream(self.device)
-            self.comm = torch.cuda.Stream(self.device) if self.collective else None
+            self.comm = _side_stream(torch, self.device) if self.collective else None
             self.gathered = [torch.cuda.Event(), torch.cuda.Event()]     # for the caller (done_event): recorded on the side stream
             self._light = None
             if self.collective:
@@ -135,16 +149,6 @@ class ShardedFlow(object):
 
     def _step(self, x_local, b, m):
         torch = self.torch
-        if self.cuda and self.collective and self._recorded[b]:
-            # The gather that read ys[b] two steps ago must be done before the kernels write ys[b] again.  It almost always
-            # is, long ago: ask first (non-blocking) and spare the kernels' queue a barrier packet in front of its next
-            # launch (4.5 us, tools/ubench/event_gap.hip); only a gather still in flight gets the device-side wait.
-            L = self._capi.lib()
-            q = L.hg_event_query(self._light[b])
-            if q < 0:
-                self._capi.check(q)
-            if q == 0:
-                self._capi.check(L.hg_stream_wait_event(self.stream.cuda_stream, self._light[b]))
         if m < self._filled[b]:         # a fuller step used this buffer before: its rows m.. must not be published again
             if self.cuda:
                 with torch.cuda.stream(self.stream):
@@ -158,6 +162,18 @@ class ShardedFlow(object):
             return self.ys[b]
         if self.cuda:
             L = self._capi.lib()
+            # The NEXT step writes ys[1 - b]; the gather that read it (last step's) must be done before.  It almost always is,
+            # long ago: ask first (non-blocking).  If not, the wait goes HERE, right in front of the record below, not in front of
+            # the next step's first launch: a wait attaches to the next command of the stream, and a kernel dispatch cannot carry
+            # a dependency — the runtime then puts a barrier packet of its own in front of it (the round-3 trace: two barrier
+            # packets between two steps' kernels, 13 us) — while the record's marker packet can.
+            nb = 1 - b
+            if self._recorded[nb]:
+                q = L.hg_event_query(self._light[nb])
+                if q < 0:
+                    self._capi.check(q)
+                if q == 0:
+                    self._capi.check(L.hg_stream_wait_event(self.stream.cuda_stream, self._light[nb]))
             self._capi.check(L.hg_event_record(self._light[2], self.stream.cuda_stream))
             self._capi.check(L.hg_stream_wait_event(self.comm.cuda_stream, self._light[2]))
             with torch.cuda.stream(self.comm):

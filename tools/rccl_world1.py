@@ -19,8 +19,11 @@ flow = Flow.from_blob(blob, device=0, output_dtype=np.float32)
 dev = torch.device("cuda", 0)
 rows = 4096
 x = torch.from_numpy(synth.make_subimages(rows, 128, dtype=np.float32)).to(dev)
-for name, coll in (("collective_free", False), ("rccl_world1", True), ("collective_free_again", False)):
-    sf = ShardedFlow.for_flow(flow, 20, rows, dev, collective=coll)
+VARIANTS = {"free": ("collective_free", False, None), "ordinary": ("rccl_world1, ordinary hand-off event", True, False),
+            "light": ("rccl_world1, device-scope hand-off event", True, True)}
+order = sys.argv[2].split(",") if len(sys.argv) > 2 else ["free", "ordinary", "light", "free"]
+for name, coll, light in [VARIANTS[k] for k in order]:
+    sf = ShardedFlow.for_flow(flow, 20, rows, dev, collective=coll, light_events=light)
     for _ in range(300):
         sf.step(x)
     sf.wait()
@@ -28,5 +31,5 @@ for name, coll in (("collective_free", False), ("rccl_world1", True), ("collecti
     for _ in range(steps):
         sf.step(x)
     sf.wait()
-    print("%-22s %.4f ms/step" % (name, (time.perf_counter() - t0) / steps * 1e3), flush=True)
+    print("%-44s %.4f ms/step" % (name, (time.perf_counter() - t0) / steps * 1e3), flush=True)
 dist.destroy_process_group()
