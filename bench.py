@@ -32,7 +32,7 @@ SIDE = 128
 PRESET = "U11L-128"
 PEAK_MFMA_F32_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0
-TRAFFIC_PROFILE = "r03_traffic.json"   # committed PMC summary the roofline's `traffic` is read from
+TRAFFIC_PROFILE = "r04_traffic.json"   # committed PMC summary the roofline's `traffic` is read from
 
 
 def cpu_baseline(nodes, n=256, reps=6):

@@ -125,8 +125,10 @@ def test_ragged_blocks_and_stale_rows(rccl_world1):
 
 
 def test_collective_step_costs_no_more_than_collective_free(rccl_world1):
-    """World-1 RCCL step time beside the collective-free one (the gather of step i runs under step i + 1): reported,
-    and bounded loosely — a serialised gather cost +39 us per 0.64 ms step in round 1."""
+    """World-1 RCCL step time beside the collective-free one (the gather of step i runs under step i + 1): reported, and
+    bounded — the hand-off costs 13-16 us per step when the side stream shares the kernels' hardware queue (every
+    ShardedFlow of a process uses the same side stream: profiles/r04_rccl_world1.txt); a second side stream cost +33 us in
+    round 3, a serialised gather +39 us in round 1."""
     import time
     import torch
     from pyfaceanalysis_amd import synth
@@ -148,7 +150,7 @@ def test_collective_step_costs_no_more_than_collective_free(rccl_world1):
         res[name] = (time.perf_counter() - t0) / 400 * 1e3
     print("ShardedFlow.step, 4096 rows U11L-128, ms/step:", {k: round(v, 4) for k, v in res.items()})
     base = min(res["collective_free"], res["collective_free_again"])
-    assert res["rccl_world1"] <= base * 1.10 + 0.02, res
+    assert res["rccl_world1"] <= base + 0.025, res
     flow.close()
 
 
