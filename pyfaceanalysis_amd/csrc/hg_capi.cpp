@@ -284,7 +284,19 @@ struct HipSink final : hg::PipeSink {
 
     void unpack(int P) {      // features of pass P: pinned slot -> caller rows
         const int b = P % NB;
-        HG_HIP(hipEventSynchronize(rep.ev_out[b]));
+        // poll before blocking: hipEventSynchronize puts the thread to sleep and the wake-up costs 20-40 us — a third of a small call
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0;; ++spins) {
+            const hipError_t q = hipEventQuery(rep.ev_out[b]);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) HG_HIP(q);
+            (void)hipGetLastError();
+            if ((spins & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
+                HG_HIP(hipEventSynchronize(rep.ev_out[b]));
+                break;
+            }
+            hg::cpu_relax();
+        }
         const int64_t r0 = pass_rows[(size_t)P].first, m = pass_rows[(size_t)P].second;
         const char* src = (const char*)rep.hy[b];
         char* dst = y + (size_t)r0 * ldy * ys;
@@ -314,9 +326,10 @@ struct HipSink final : hg::PipeSink {
         }
         if (P >= NB) unpack_upto(P - NB + 1);
         if (timed) stamp();
-        run_on_device(f, rep.dx[b].p, wire_dtype, rows, in_dim, rep.dy[b].p, y_dtype, y_cols, y_cols, rep.compute, &rep);
+        // the last kernel of the pass stores the features straight into the pinned slot (device-visible host memory: 160 bytes per
+        // row over PCIe), no copy command behind it
+        run_on_device(f, rep.dx[b].p, wire_dtype, rows, in_dim, rep.hy[b], y_dtype, y_cols, y_cols, rep.compute, &rep);
         if (timed) stamp();
-        HG_HIP(hipMemcpyAsync(rep.hy[b], rep.dy[b].p, (size_t)rows * y_cols * ys, hipMemcpyDeviceToHost, rep.compute));
         HG_HIP(hipEventRecord(rep.ev_out[b], rep.compute));
         pass_rows.emplace_back(row_base + r0, rows);
     }
@@ -413,7 +426,6 @@ void run_host_rows_impl(hg_flow* f, Replica& rep, const void* x, int x_dtype, in
     rep.need_pinned(ring_want, (size_t)widest_pass * y_cols * ys);
     for (int b = 0; b < NB; ++b) {
         rep.dx[b].alloc(std::min<size_t>(pass_bytes, (size_t)((n + 15) / 16 * 16) * row_given));
-        rep.dy[b].alloc((size_t)widest_pass * y_cols * ys);
     }
     rep.exec->reserve(widest_pass);
 
