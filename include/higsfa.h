@@ -98,9 +98,11 @@ int hg_flow_reserve(hg_flow* f, int64_t max_rows);
  * y: n rows, the first y_cols (<= output_dim) columns, row stride ldy elements.  The caller
  * usually wants only the first classifier.input_dim columns (FaceDetectUpdated.py:709,719).
  * n == 0 is valid and a no-op (reference guards len(subimages_arr) > 0 at :694).
- * Synchronous: returns after y is complete.  Rows go through pinned double-buffered staging (the copy of chunk
- * i+1 overlaps the kernels of chunk i); float32 / float64 chunks whose values are all integers 0..255 — what
- * images_asarray produces (face_analysis.py:786) — cross PCIe as uint8, which changes no output bit. */
+ * Synchronous: returns after y is complete.  A pool of host threads on the memory node of the rows packs them while the
+ * device works on earlier rows (passes of a few hundred rows, sized by a planner): straight into device memory on large-BAR
+ * devices, through a pinned ring and two copy queues otherwise; float32 / float64 rows whose values are all integers 0..255 —
+ * what images_asarray produces (face_analysis.py:786) — cross PCIe as uint8, which changes no output bit; from the first
+ * row that holds anything else the rest of the call travels in the caller's own type. */
 int hg_flow_execute(hg_flow* f, const void* x, int x_dtype, int64_t n, int64_t ldx,
                     void* y, int y_dtype, int64_t y_cols, int64_t ldy);
 

@@ -1314,7 +1314,8 @@ public:
             if (tail_begin_ >= 0 && (int)si == tail_start(n_tiles)) {
                 // the top of the hierarchy as one launch that ends in the caller's rows (hg_fused_tail.hip)
                 TailParams TP = tail_params((int)si, cur, n_tiles, y, y_dtype, y_cols, ldy, n);
-                const int T = (n_tiles >= 512 && tail_waves(TP) <= 8) ? 2 : 1;
+                // two tiles per workgroup only for narrow tops on long batches, and only while their doubled LDS image fits
+                const int T = (n_tiles >= 512 && tail_waves(TP) <= 8 && tail_lds_bytes(TP, 2) <= (size_t)160 * 1024) ? 2 : 1;
                 launch_tail(TP, T, st);
                 if (ev)
                     for (size_t k = si; k <= stages_.size(); ++k) HG_HIP(hipEventRecord(ev[e++], st));   // the first event carries the launch's time

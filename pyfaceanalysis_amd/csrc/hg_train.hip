@@ -5,8 +5,10 @@
 //     mean = E[x],   B = Cov(x),   A = Cov(x[t+1] - x[t]),   solve A w = lambda B w,
 //     eigenvalues ascending (slowest first), eigenvectors normalised w' B w = 1.
 // Statistics: hand-written HIP kernel, fp64 accumulation (MDP accumulates in float64 too), one workgroup per
-// (node, sample split), partial sums reduced in a fixed order (bit-reproducible).  Solve: rocSOLVER
-// dsygvd_strided_batched (a plain library call on small dense matrices).
+// (node, sample split), partial sums reduced in a fixed order (bit-reproducible); nodes of <= 16 inputs on the fp64 matrix
+// cores (v_mfma_f64_16x16x4_f64).  Solve: a hand-written one-wave-per-node kernel for nodes of <= 16 inputs (Cholesky of B,
+// C = L^-1 A L^-T, cyclic Jacobi, back-substitution, sort: < 0.2 ms for 1024 nodes), rocSOLVER dsygvj for wider nodes
+// (HIGSFA_SYGVJ / HIGSFA_SYGVD force the library solvers); include/higsfa.h and DESIGN.md §8 say the same.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
