@@ -37,20 +37,24 @@ namespace {
 // (o += a per output pixel); to land on the same pixel in every case each thread repeats that sum from the start
 // of its axis — O(m) dependent adds for the last entry instead of one thread walking all m entries with a
 // conversion, two compares and a store per step.
+__device__ __forceinline__ int32_t extent_entry(const double* __restrict__ box, int e, int w, int h, int fw, int fh) {
+    const int axis = e >= w ? 1 : 0, i = axis ? e - w : e;
+    const double lo = box[axis], hi = box[2 + axis];
+    const int m = axis ? h : w, lim = axis ? fh : fw;
+    const double a = (hi - lo) / m;
+    double o = lo + a * 0.5;
+    for (int k = 0; k < i; ++k) o += a;
+    const int v = o < 0.0 ? -1 : (int)o;
+    return (v >= 0 && v < lim) ? v : -1;
+}
+
 __global__ void k_extent_tables(const double* __restrict__ boxes, int64_t n, int w, int h, int fw, int fh, int32_t* __restrict__ tabs) {
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int wh = w + h;
     if (id >= n * wh) return;
     const int64_t b = id / wh;
     const int e = (int)(id - b * wh);
-    const int axis = e >= w ? 1 : 0, i = axis ? e - w : e;
-    const double lo = boxes[b * 4 + axis], hi = boxes[b * 4 + 2 + axis];
-    const int m = axis ? h : w, lim = axis ? fh : fw;
-    const double a = (hi - lo) / m;
-    double o = lo + a * 0.5;
-    for (int k = 0; k < i; ++k) o += a;
-    const int v = o < 0.0 ? -1 : (int)o;
-    tabs[b * wh + e] = (v >= 0 && v < lim) ? v : -1;
+    tabs[b * wh + e] = extent_entry(boxes + b * 4, e, w, h, fw, fh);
 }
 
 // One workgroup per (group of output rows, box): no index divisions, the row's source line and the column table are
@@ -111,10 +115,7 @@ __device__ __forceinline__ int32_t fix16(double v) {        // Geometry.c FIX():
     return x >= 0.0 ? (int32_t)x : (int32_t)floor(x);
 }
 
-__global__ void k_rot_coefs(const double* __restrict__ boxes, const double* __restrict__ angs, int64_t n, int fw, int fh,
-                            RotCoef* __restrict__ out) {
-    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= n) return;
+__device__ __forceinline__ RotCoef rot_coef_of(const double* __restrict__ boxes, const double* __restrict__ angs, int64_t b, int fw, int fh) {
     RotCoef rc{};
     double a = fmod(angs[b], 360.0);                 // Python's float %: result carries the divisor's sign
     if (a < 0.0) a += 360.0;
@@ -146,64 +147,84 @@ __global__ void k_rot_coefs(const double* __restrict__ boxes, const double* __re
             rc.A[5] = fix16(__dadd_rn(__dadd_rn(m5, __dmul_rn(m3, 0.5)), __dmul_rn(m4, 0.5)));
         }
     }
-    out[b] = rc;
+    return rc;
+}
+
+__global__ void k_rot_coefs(const double* __restrict__ boxes, const double* __restrict__ angs, int64_t n, int fw, int fh,
+                            RotCoef* __restrict__ out) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n) return;
+    out[b] = rot_coef_of(boxes, angs, b, fw, fh);
 }
 
 // Rotated windows: per pixel, EXTENT table -> pixel of the rotated frame -> source pixel.  The frame (<= a few MB)
 // sits in L2; the access pattern is a rotated scan line.
+// One output row y of one box: EXTENT table (t[0..w) columns, t[w..w+h) rows) -> pixel of the rotated frame -> source pixel.
+// uint8 windows: four pixels per thread and one 32-bit store (round 4: byte stores made the first stage's 1738 windows 79 us).
+template <typename FT, typename OT>
+__device__ __forceinline__ void gather_rot_row(const FT* __restrict__ frame, int64_t ld, int fw, int fh, const int32_t* t, const RotCoef& rc, int y,
+                                               int w, OT* __restrict__ dst, bool packed, int tx, int ntx) {
+    const int yr = t[w + y];
+    double yo = 0.0;
+    int ys2 = -1;
+    if (rc.mode == 2 && yr >= 0) {      // ImagingScaleAffine on the rotated frame: yo = a5 + a4 / 2, then += a4 per row
+        yo = __dadd_rn(rc.m5, __dmul_rn(rc.m4, 0.5));
+        for (int k = 0; k < yr; ++k) yo = __dadd_rn(yo, rc.m4);
+        ys2 = yo < 0.0 ? -1 : (int)yo;
+        if (ys2 >= fh) ys2 = -1;
+    }
+    auto pixel = [&](int x) -> OT {
+        const int xr = t[x];
+        int xs = -1, ys = -1;
+        if (xr >= 0 && yr >= 0) {
+            if (rc.mode == 0) {
+                xs = xr; ys = yr;
+            } else if (rc.mode == 1) {
+                const int64_t xx = (int64_t)rc.A[2] + (int64_t)yr * rc.A[1] + (int64_t)xr * rc.A[0];
+                const int64_t yy = (int64_t)rc.A[5] + (int64_t)yr * rc.A[4] + (int64_t)xr * rc.A[3];
+                xs = (int)(xx >> 16); ys = (int)(yy >> 16);
+            } else if (rc.mode == 2) {
+                double xo = __dadd_rn(rc.m2, __dmul_rn(rc.m0, 0.5));
+                for (int k = 0; k < xr; ++k) xo = __dadd_rn(xo, rc.m0);
+                xs = xo < 0.0 ? -1 : (int)xo;
+                ys = ys2;
+            }
+        }
+        const bool in = xs >= 0 && xs < fw && ys >= 0 && ys < fh;
+        return in ? (OT)frame[(int64_t)ys * ld + xs] : (OT)0;
+    };
+    if constexpr (sizeof(OT) == 1) {
+        if (packed) {
+            for (int x = tx * 4; x < w; x += ntx * 4) {
+                uint32_t pk = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pk |= (uint32_t)(uint8_t)pixel(x + q) << (8 * q);
+                *(uint32_t*)(dst + x) = pk;
+            }
+            return;
+        }
+    }
+    for (int x = tx; x < w; x += ntx) dst[x] = pixel(x);
+}
+
+// Rotated windows, tables from memory (k_extent_tables, k_rot_coefs): the frame (<= a few MB) sits in L2; the access pattern is a
+// rotated scan line.
 template <typename FT, typename OT>
 __global__ void __launch_bounds__(256) k_extent_gather_rot(const FT* __restrict__ frame, int64_t ld, int fw, int fh, const int32_t* __restrict__ tabs,
                                                             const RotCoef* __restrict__ rot, int64_t n, int w, int h, OT* __restrict__ out, int64_t ldo) {
     const int y = blockIdx.x * blockDim.y + threadIdx.y;
     if (y >= h) return;
+    const bool packed = sizeof(OT) == 1 && (w & 3) == 0 && (ldo & 3) == 0 && ((uintptr_t)out & 3) == 0;
     for (int64_t b = blockIdx.y; b < n; b += gridDim.y) {
         const RotCoef rc = rot[b];
-        const int32_t* t = tabs + b * (w + h);
-        const int yr = t[w + y];
-        OT* dst = out + b * ldo + (int64_t)y * w;
-        double yo = 0.0;
-        int ys2 = -1;
-        if (rc.mode == 2 && yr >= 0) {      // ImagingScaleAffine on the rotated frame: yo = a5 + a4 / 2, then += a4 per row
-            yo = __dadd_rn(rc.m5, __dmul_rn(rc.m4, 0.5));
-            for (int k = 0; k < yr; ++k) yo = __dadd_rn(yo, rc.m4);
-            ys2 = yo < 0.0 ? -1 : (int)yo;
-            if (ys2 >= fh) ys2 = -1;
-        }
-        auto pixel = [&](int x) -> OT {
-            const int xr = t[x];
-            int xs = -1, ys = -1;
-            if (xr >= 0 && yr >= 0) {
-                if (rc.mode == 0) {
-                    xs = xr; ys = yr;
-                } else if (rc.mode == 1) {
-                    const int64_t xx = (int64_t)rc.A[2] + (int64_t)yr * rc.A[1] + (int64_t)xr * rc.A[0];
-                    const int64_t yy = (int64_t)rc.A[5] + (int64_t)yr * rc.A[4] + (int64_t)xr * rc.A[3];
-                    xs = (int)(xx >> 16); ys = (int)(yy >> 16);
-                } else if (rc.mode == 2) {
-                    double xo = __dadd_rn(rc.m2, __dmul_rn(rc.m0, 0.5));
-                    for (int k = 0; k < xr; ++k) xo = __dadd_rn(xo, rc.m0);
-                    xs = xo < 0.0 ? -1 : (int)xo;
-                    ys = ys2;
-                }
-            }
-            const bool in = xs >= 0 && xs < fw && ys >= 0 && ys < fh;
-            return in ? (OT)frame[(int64_t)ys * ld + xs] : (OT)0;
-        };
-        if constexpr (sizeof(OT) == 1) {
-            // four pixels per thread and one 32-bit store (round 4: byte stores made the first stage's 1738 windows 79 us)
-            if ((w & 3) == 0 && (ldo & 3) == 0 && ((uintptr_t)out & 3) == 0) {
-                for (int x = threadIdx.x * 4; x < w; x += blockDim.x * 4) {
-                    uint32_t pk = 0;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) pk |= (uint32_t)(uint8_t)pixel(x + q) << (8 * q);
-                    *(uint32_t*)(dst + x) = pk;
-                }
-                continue;
-            }
-        }
-        for (int x = threadIdx.x; x < w; x += blockDim.x) dst[x] = pixel(x);
+        gather_rot_row<FT, OT>(frame, ld, fw, fh, tabs + b * (w + h), rc, y, w, out + b * ldo + (int64_t)y * w, packed, threadIdx.x, blockDim.x);
     }
 }
+
+// (Round 4 also measured tables + coefficients + gather as ONE launch, a workgroup per box building its tables and coefficients in
+// LDS: 48.6 us against 38.5 for the first stage's 1738 windows and 25 against 21 for a few hundred — one thread's double-precision
+// fmod / cos / sin and the dependent additions of the tables sit on every workgroup's critical path instead of being spread over
+// a launch of their own.  Not kept.)
 
 template <typename F>
 int guarded(F&& fn) {
