@@ -724,6 +724,9 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(nodes)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+            op = out["cpu_baseline"].get("optimised_port")
+            if op and op.get("value"):      # the honest CPU point: flat float64 C port, AVX2 + OpenMP, on `cores` of the box's cores
+                out["speedup_vs_optimised_c_port"] = {"ratio": value / op["value"], "cores": op.get("cores")}
         print(json.dumps(out), flush=True)
     flow.close()
     if distributed:

@@ -88,28 +88,43 @@ k_gauss_regression(const T* __restrict__ x, int64_t ldx, int64_t n, int K, int d
 // q += t_i (x_i - m_c[i]) over a class's d rows in the order — and with the very expression — of the loop above and finishes
 // exactly as above: the same operations in the same order on every value, hence the same bits (tested).  For K d <= 4096
 // (32 KiB of LDS).
-template <typename T>
+template <typename T, int R>
 __global__ void __launch_bounds__(256)
 k_gauss_regression_wg(const T* __restrict__ x, int64_t ldx, int64_t n, int K, int d, const double* __restrict__ means,
                       const double* __restrict__ inv_covs, const double* __restrict__ logw, const double* __restrict__ avg,
                       double* __restrict__ out_reg, double* __restrict__ out_std) {
+    // R rows per workgroup: a matrix row read from L2 once serves R feature vectors (a launch on 348 rows of the 50-class
+    // regressors moved 55 MB through L2 at one row per workgroup); wave r finishes row r
     extern __shared__ double lds_g[];
-    double* xs = lds_g;              // [64]
-    double* term = lds_g + 64;       // [K * d]
-    const int64_t row = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63;
-    if (tid < d) xs[tid] = (double)x[row * ldx + tid];
+    double* xs = lds_g;                       // [R][64]
+    double* term = lds_g + R * 64;            // [R][K * d]
+    const int64_t row0 = (int64_t)blockIdx.x * R;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kd = K * d;
+    for (int e = tid; e < R * d; e += blockDim.x) {
+        const int r = e / d, j = e - r * d;
+        xs[r * 64 + j] = row0 + r < n ? (double)x[(row0 + r) * ldx + j] : 0.0;
+    }
     __syncthreads();
-    for (int e = tid; e < K * d; e += blockDim.x) {
+    for (int e = tid; e < kd; e += blockDim.x) {
         const int c = e / d, i = e - c * d;
         const double* m = means + (size_t)c * d;
         const double* S = inv_covs + (size_t)c * d * d + (size_t)i * d;
-        double t = 0;
-        for (int j = 0; j < d; ++j) t += S[j] * (xs[j] - m[j]);
-        term[e] = t;
+        double t[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) t[r] = 0;
+        for (int j = 0; j < d; ++j) {
+            const double sj = S[j], mj = m[j];
+#pragma unroll
+            for (int r = 0; r < R; ++r) t[r] += sj * (xs[r * 64 + j] - mj);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) term[r * kd + e] = t[r];
     }
     __syncthreads();
-    if (tid >= 64) return;
+    if (wave >= R || row0 + wave >= n) return;
+    const double* xr = xs + wave * 64;
+    const double* tr = term + wave * kd;
     double lmax = -INFINITY;
     double lp[kMaxClasses / 64];
 #pragma unroll
@@ -119,7 +134,7 @@ k_gauss_regression_wg(const T* __restrict__ x, int64_t ldx, int64_t n, int K, in
         if (c < K) {
             const double* m = means + (size_t)c * d;
             double q = 0;
-            for (int i = 0; i < d; ++i) q += term[c * d + i] * (xs[i] - m[i]);      // the expression of the kernel above, term = its t
+            for (int i = 0; i < d; ++i) q += tr[c * d + i] * (xr[i] - m[i]);      // the expression of the kernel above, term = its t
             v = logw[c] - 0.5 * q;
         }
         lp[s] = v;
@@ -144,8 +159,8 @@ k_gauss_regression_wg(const T* __restrict__ x, int64_t ldx, int64_t n, int K, in
     }
     if (lane == 0) {
         const double reg = swa / sw;
-        out_reg[row] = reg;
-        if (out_std) out_std[row] = sqrt(fmax(swa2 / sw - reg * reg, 0.0));
+        out_reg[row0 + wave] = reg;
+        if (out_std) out_std[row0 + wave] = sqrt(fmax(swa2 / sw - reg * reg, 0.0));
     }
 }
 
@@ -169,13 +184,22 @@ void launch(hg_gauss* g, const void* x, int x_dtype, int64_t n, int64_t ldx, dou
     if (x_dtype != HG_F32 && x_dtype != HG_F64) hg::fail(HG_ERR_ARG, "feature dtype must be HG_F32 or HG_F64");
     const bool no_wg = getenv("HIGSFA_GAUSS_WAVE") != nullptr;      // tests: the one-wave-per-row kernel only (read per call)
     if ((int64_t)g->K * g->d <= 4096 && !no_wg) {
-        const size_t lds = (size_t)(64 + g->K * g->d) * 8;
-        if (x_dtype == HG_F32)
-            hipLaunchKernelGGL(k_gauss_regression_wg<float>, (unsigned)n, 256, lds, st, (const float*)x, ldx, n, g->K, g->d, (const double*)g->means.p,
-                               (const double*)g->inv_covs.p, (const double*)g->logw.p, (const double*)g->avg.p, reg, sd);
-        else
-            hipLaunchKernelGGL(k_gauss_regression_wg<double>, (unsigned)n, 256, lds, st, (const double*)x, ldx, n, g->K, g->d, (const double*)g->means.p,
-                               (const double*)g->inv_covs.p, (const double*)g->logw.p, (const double*)g->avg.p, reg, sd);
+        // four rows per workgroup from 256 rows on (fewer: one row per workgroup keeps more of the chip busy), while the LDS image fits
+        const bool r4 = n >= 256 && (int64_t)g->K * g->d <= 1536;
+        const int R = r4 ? 4 : 1;
+        const size_t lds = (size_t)R * (64 + g->K * g->d) * 8;
+        const unsigned grid = (unsigned)((n + R - 1) / R);
+#define HG_GAUSS_WG(TT, RR)                                                                                                                   \
+    hipLaunchKernelGGL((k_gauss_regression_wg<TT, RR>), grid, 256, lds, st, (const TT*)x, ldx, n, g->K, g->d, (const double*)g->means.p, \
+                       (const double*)g->inv_covs.p, (const double*)g->logw.p, (const double*)g->avg.p, reg, sd)
+        if (x_dtype == HG_F32) {
+            if (r4) HG_GAUSS_WG(float, 4);
+            else HG_GAUSS_WG(float, 1);
+        } else {
+            if (r4) HG_GAUSS_WG(double, 4);
+            else HG_GAUSS_WG(double, 1);
+        }
+#undef HG_GAUSS_WG
         HG_HIP(hipGetLastError());
         return;
     }

@@ -341,6 +341,11 @@ def test_gaussian_regression(native_lib):
         finally:
             del os.environ["HIGSFA_GAUSS_WAVE"]
         assert np.array_equal(reg_w, reg) and np.array_equal(std_w, std)
+        # from 256 rows on a workgroup takes four rows: the same bits row by row, ragged last workgroup included
+        reps = -(-301 // len(x))
+        xx = np.tile(x, (reps, 1))[:301]
+        reg4, std4 = clf.regression(xx, estimate_std=True)
+        assert np.array_equal(reg4, np.tile(reg, reps)[:301]) and np.array_equal(std4, np.tile(std, reps)[:301])
         clf.close()
     # a classifier beyond the workgroup form (K d > 4096): 300 classes x 20 features, against the C restatement
     rng = np.random.default_rng(5)
