@@ -245,3 +245,11 @@ def test_ordering_event_entry_points_reject_null(native_lib):
     assert native_lib.hg_stream_wait_event(None, None) == _capi.HG_ERR_ARG
     assert native_lib.hg_event_query(None) == _capi.HG_ERR_ARG
     native_lib.hg_event_destroy(None)          # a no-op
+    import ctypes as C
+    assert native_lib.hg_event_create_on(None, 0, 1) == _capi.HG_ERR_ARG
+    h = C.c_void_p()
+    rc = native_lib.hg_event_create_on(C.byref(h), 0, 0)
+    if rc == _capi.HG_OK:                      # a box with a GPU
+        native_lib.hg_event_destroy(h)
+    else:
+        assert rc == _capi.HG_ERR_DEVICE and b"no HIP device" in native_lib.hg_last_error()
