@@ -51,6 +51,39 @@ def test_soak_ten_seconds(native_lib):
     assert bad == 0 and calls > 1000
 
 
+def test_host_path_soak_five_seconds(native_lib):
+    """The ndarray-in / ndarray-out call for 5 s with random batch sizes, types and row offsets: packers storing straight into
+    the pass buffers in device memory (write-combined stores, fence, flag, launch from another thread), six buffers rotating,
+    features stored into pinned memory by the last kernel and polled — a row left in a write-combining buffer, a kernel reading
+    a stale line of a reused buffer or a feature row read before it arrived would show as a mismatch against the rows of one
+    device-resident reference."""
+    import torch
+    from pyfaceanalysis_amd import synth
+    blob, nodes = synth.cached_preset_blob("U11L-128")
+    flow = Flow.from_blob(blob, device=0, output_dtype=np.float32)
+    x8 = synth.make_subimages(4096, 128, dtype=np.uint8)
+    dev = torch.device("cuda", 0)
+    xd = torch.from_numpy(x8).to(dev)
+    ref_d = torch.empty((4096, 20), dtype=torch.float32, device=dev)
+    flow.execute_device(xd.data_ptr(), np.dtype(np.uint8), 4096, 16384, ref_d.data_ptr(), np.float32, 20, 20, stream=torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize()
+    ref = ref_d.cpu().numpy()
+    xs = {np.uint8: x8, np.float32: x8.astype(np.float32), np.float64: x8.astype(np.float64)}
+    rng = np.random.default_rng(3)
+    t0 = time.perf_counter()
+    calls = bad = 0
+    while time.perf_counter() - t0 < 5.0:
+        n = int(rng.choice([1, 5, 16, 17, 100, 129, 340, 728, 1000, 1738, 2049, 4096]))
+        dt = [np.uint8, np.float32, np.float64][int(rng.integers(0, 3))]
+        off = int(rng.integers(0, 4096 - n + 1))
+        y = flow.execute(xs[dt][off:off + n], n_cols=20)
+        bad += not np.array_equal(y, ref[off:off + n])
+        calls += 1
+    print("host-path soak: %d calls in %.1f s, mismatching calls: %d" % (calls, time.perf_counter() - t0, bad))
+    flow.close()
+    assert bad == 0 and calls > 500
+
+
 def test_wide_fuzz_fifty_hierarchies(native_lib):
     bad, tails, n = [], 0, 0
     for kind, maker, seeds in (("net", helpers.fuzz_net, range(100, 130)), ("prod", helpers.fuzz_product_net, range(100, 112)),
