@@ -221,7 +221,8 @@ __global__ void k_cascade_init(int n, const double* __restrict__ orig_coords, do
     oidx[i] = i;
 }
 
-__global__ void __launch_bounds__(1024) k_cascade_stage(int type, hg_cascade_consts c, StageArrays A, int32_t* host_count, int seq, HostResults H) {
+// The body for ONE workgroup of any size up to 1024 threads (k_cascade_stage: 1024; the last workgroup of k_cascade_stage_reg: 256).
+__device__ __forceinline__ void cascade_stage_body(int type, const hg_cascade_consts& c, const StageArrays& A, int32_t* host_count, int seq, const HostResults& H) {
     __shared__ int wsum[16];
     __shared__ int base;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -287,6 +288,15 @@ __global__ void __launch_bounds__(1024) k_cascade_stage(int type, hg_cascade_con
         if (host_count) publish_count(host_count, cnt, seq);
     }
 }
+
+__global__ void __launch_bounds__(1024) k_cascade_stage(int type, hg_cascade_consts c, StageArrays A, int32_t* host_count, int seq, HostResults H) {
+    cascade_stage_body(type, c, A, host_count, seq, H);
+}
+
+// (Round 4 measured regression AND glue of a stage as ONE launch — a workgroup per R candidates runs the regression of its rows,
+// publishes them with write-through stores, draws a ticket, and the workgroup with the last ticket runs the glue: 16 us per stage
+// against 8.7 + 5.4 for the two launches (1.57 against 1.49 ms per frame; with a device-scope fence instead of write-through
+// stores 1.66: the fence writes back the whole L2 of the workgroup's XCD).  Not kept.)
 
 // The same stage for batches of many frames' windows (the single workgroup above walks 1024 candidates per step): two launches
 // of one workgroup per kChunk candidates.  `mark` updates every candidate IN PLACE in the cur arrays (nobody else reads them any

@@ -12,6 +12,7 @@
 #include <cmath>
 
 #include "hg_common.hpp"
+#include "hg_gauss_dev.hpp"
 
 struct hg_gauss {
     int K = 0, d = 0, device = -1;
@@ -19,11 +20,24 @@ struct hg_gauss {
     hg::DevBuf sx, sreg, sstd;              // host-call staging
 };
 
+namespace hg {
+GaussParams gauss_params(const hg_gauss* g) {
+    GaussParams G;
+    G.K = g->K;
+    G.d = g->d;
+    G.means = (const double*)g->means.p;
+    G.inv_covs = (const double*)g->inv_covs.p;
+    G.logw = (const double*)g->logw.p;
+    G.avg = (const double*)g->avg.p;
+    return G;
+}
+}  // namespace hg
+
 namespace {
 
 thread_local std::string g_gauss_error;
 
-constexpr int kMaxClasses = 1024;
+constexpr int kMaxClasses = hg::kGaussMaxClasses;
 
 template <typename T>
 __global__ void __launch_bounds__(64)
@@ -81,87 +95,12 @@ k_gauss_regression(const T* __restrict__ x, int64_t ldx, int64_t n, int K, int d
     }
 }
 
-// The same regression with the quadratic forms spread over a workgroup (round 4).  Above, lane c walks the d x d matrix of its
-// class alone — 400 dependent steps for the pose regressors (50 classes, 20 features), with every lane of a load on another
-// cache line: 25-32 us for a call on a handful of rows, nine times per frame.  Here thread (c, i) of four waves computes
-// t_i = sum_j S_c[i][j] (x_j - m_c[j]) from one contiguous matrix row and leaves it in LDS; wave 0 then forms
-// q += t_i (x_i - m_c[i]) over a class's d rows in the order — and with the very expression — of the loop above and finishes
-// exactly as above: the same operations in the same order on every value, hence the same bits (tested).  For K d <= 4096
-// (32 KiB of LDS).
+// The workgroup form (round 4): hg_gauss_dev.hpp, shared with the cascade's stage kernel.
 template <typename T, int R>
 __global__ void __launch_bounds__(256)
-k_gauss_regression_wg(const T* __restrict__ x, int64_t ldx, int64_t n, int K, int d, const double* __restrict__ means,
-                      const double* __restrict__ inv_covs, const double* __restrict__ logw, const double* __restrict__ avg,
-                      double* __restrict__ out_reg, double* __restrict__ out_std) {
-    // R rows per workgroup: a matrix row read from L2 once serves R feature vectors (a launch on 348 rows of the 50-class
-    // regressors moved 55 MB through L2 at one row per workgroup); wave r finishes row r
+k_gauss_regression_wg(const T* __restrict__ x, int64_t ldx, int64_t n, hg::GaussParams G, double* __restrict__ out_reg, double* __restrict__ out_std) {
     extern __shared__ double lds_g[];
-    double* xs = lds_g;                       // [R][64]
-    double* term = lds_g + R * 64;            // [R][K * d]
-    const int64_t row0 = (int64_t)blockIdx.x * R;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int kd = K * d;
-    for (int e = tid; e < R * d; e += blockDim.x) {
-        const int r = e / d, j = e - r * d;
-        xs[r * 64 + j] = row0 + r < n ? (double)x[(row0 + r) * ldx + j] : 0.0;
-    }
-    __syncthreads();
-    for (int e = tid; e < kd; e += blockDim.x) {
-        const int c = e / d, i = e - c * d;
-        const double* m = means + (size_t)c * d;
-        const double* S = inv_covs + (size_t)c * d * d + (size_t)i * d;
-        double t[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) t[r] = 0;
-        for (int j = 0; j < d; ++j) {
-            const double sj = S[j], mj = m[j];
-#pragma unroll
-            for (int r = 0; r < R; ++r) t[r] += sj * (xs[r * 64 + j] - mj);
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) term[r * kd + e] = t[r];
-    }
-    __syncthreads();
-    if (wave >= R || row0 + wave >= n) return;
-    const double* xr = xs + wave * 64;
-    const double* tr = term + wave * kd;
-    double lmax = -INFINITY;
-    double lp[kMaxClasses / 64];
-#pragma unroll
-    for (int s = 0; s < kMaxClasses / 64; ++s) {
-        const int c = lane + 64 * s;
-        double v = -INFINITY;
-        if (c < K) {
-            const double* m = means + (size_t)c * d;
-            double q = 0;
-            for (int i = 0; i < d; ++i) q += tr[c * d + i] * (xr[i] - m[i]);      // the expression of the kernel above, term = its t
-            v = logw[c] - 0.5 * q;
-        }
-        lp[s] = v;
-        lmax = fmax(lmax, v);
-    }
-    for (int o = 32; o > 0; o >>= 1) lmax = fmax(lmax, __shfl_xor(lmax, o));
-    double sw = 0, swa = 0, swa2 = 0;
-#pragma unroll
-    for (int s = 0; s < kMaxClasses / 64; ++s) {
-        const int c = lane + 64 * s;
-        if (c < K) {
-            const double w = exp(lp[s] - lmax), a = avg[c];
-            sw += w;
-            swa += w * a;
-            swa2 += w * a * a;
-        }
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        sw += __shfl_xor(sw, o);
-        swa += __shfl_xor(swa, o);
-        swa2 += __shfl_xor(swa2, o);
-    }
-    if (lane == 0) {
-        const double reg = swa / sw;
-        out_reg[row0 + wave] = reg;
-        if (out_std) out_std[row0 + wave] = sqrt(fmax(swa2 / sw - reg * reg, 0.0));
-    }
+    hg::gauss_rows_wg<T, R>(x, ldx, n, (int64_t)blockIdx.x * R, G, lds_g, out_reg, out_std);
 }
 
 template <typename F>
@@ -189,9 +128,8 @@ void launch(hg_gauss* g, const void* x, int x_dtype, int64_t n, int64_t ldx, dou
         const int R = r4 ? 4 : 1;
         const size_t lds = (size_t)R * (64 + g->K * g->d) * 8;
         const unsigned grid = (unsigned)((n + R - 1) / R);
-#define HG_GAUSS_WG(TT, RR)                                                                                                                   \
-    hipLaunchKernelGGL((k_gauss_regression_wg<TT, RR>), grid, 256, lds, st, (const TT*)x, ldx, n, g->K, g->d, (const double*)g->means.p, \
-                       (const double*)g->inv_covs.p, (const double*)g->logw.p, (const double*)g->avg.p, reg, sd)
+        const hg::GaussParams G = hg::gauss_params(g);
+#define HG_GAUSS_WG(TT, RR) hipLaunchKernelGGL((k_gauss_regression_wg<TT, RR>), grid, 256, lds, st, (const TT*)x, ldx, n, G, reg, sd)
         if (x_dtype == HG_F32) {
             if (r4) HG_GAUSS_WG(float, 4);
             else HG_GAUSS_WG(float, 1);
