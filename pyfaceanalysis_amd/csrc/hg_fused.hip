@@ -420,6 +420,9 @@ bool build_stages(const TNode& root, std::vector<FStage>& stages, std::string& w
 // before the second half of the previous node, whose MFMAs (no global loads of their own) cover the L2 / HBM round trip.
 // For small nodes (layer 2: four blocks of <= 4 k-steps) the one-block-ahead stream leaves each wave waiting ~1.5k cycles
 // per block (in-kernel stamps: GEMM 1 took 6x its MFMA time); costs KBF * T * 4 registers.
+#ifndef HG_A_PINGPONG
+#define HG_A_PINGPONG 1      // (A/B switch: HIGSFA_CXXFLAGS=-DHG_A_PINGPONG=0)
+#endif
 #ifdef HIGSFA_DIAG
 #define HG_HOT(blk) ((P.whatif & 1) ? ((blk) & 1) : (blk))      // timing experiment: all input blocks from the first two of the tile row
 #else
@@ -595,6 +598,34 @@ __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
                 for (int t = 0; t < T; ++t) d4[t] = f32x4{0.f, 0.f, 0.f, 0.f};
                 unsigned long long ts0 = 0, ts1 = 0;
                 if (STAMP) ts0 = stamp_now();
+                if constexpr (FS && !REM && HG_A_PINGPONG) {
+                    // A fragments of block kbi + 1 are read from LDS BEFORE block kbi is multiplied, into the other of two register
+                    // sets (the loop body twice, so that no set is ever copied): the MFMAs of a block wait for no LDS read
+                    f32x4 a0[MT1], a1[MT1];
+#pragma unroll
+                    for (int mt = 0; mt < MT1; ++mt) a0[mt] = wA1[mt * 64];
+                    auto kstep = [&](int kbi, const f32x4 (&ac)[MT1], f32x4 (&an)[MT1]) {
+                        const bool in_node = kbi + 1 < P.kb1;
+                        const bool in_group = in_node || ln + 1 < gn;
+                        const int2 kbn = in_node ? kt[kbi + 1] : (ln + 1 < gn ? kt[P.kb1] : stab[0]);
+                        const int sbn = HG_HOT(__builtin_amdgcn_readfirstlane(kbn.x));
+                        const int nkn = __builtin_amdgcn_readfirstlane(kbn.y);
+#pragma unroll
+                        for (int t = 0; t < T; ++t) bfn[t] = P.in[(size_t)((in_group ? trow[t] : trow_nx[t]) + sbn) * 64 + lane];
+                        if (in_node) {
+#pragma unroll
+                            for (int mt = 0; mt < MT1; ++mt) an[mt] = wA1[((kbi + 1) * MT1 + mt) * 64];
+                        }
+                        gemm_block_regs<MT1, T>(ac, bf, z, nk & 255, nk >> 8);
+#pragma unroll
+                        for (int t = 0; t < T; ++t) bf[t] = bfn[t];
+                        nk = nkn;
+                    };
+                    for (int kbi = 0; kbi < P.kb1; kbi += 2) {
+                        kstep(kbi, a0, a1);
+                        if (kbi + 1 < P.kb1) kstep(kbi + 1, a1, a0);
+                    }
+                } else
                 for (int kbi = 0; kbi < P.kb1; ++kbi) {
                     const bool in_node = kbi + 1 < P.kb1;
                     const bool in_group = in_node || ln + 1 < gn;

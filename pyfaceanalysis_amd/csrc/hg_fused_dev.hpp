@@ -132,6 +132,9 @@ __device__ __forceinline__ f32x4 apply_func_uniform(int func, float expo, f32x4 
     return e;
 }
 
+#ifndef HG_POW_PREFETCH
+#define HG_POW_PREFETCH 1      // (A/B switch: HIGSFA_CXXFLAGS=-DHG_POW_PREFETCH=0)
+#endif
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 // One K-block: acc[mt][t] += A[mt] (16 x 16, four k-steps) * B[t].  `wp` points at the block's first
@@ -173,6 +176,20 @@ __device__ __forceinline__ void gemm_block(WP wp, const f32x4 (&b)[T], f32x4 (&a
                     for (int t = 0; t < T; ++t) acc[mt][t] = MFMA16(a[mt][r], b[t][r], acc[mt][t]);
             }
     }
+}
+
+// The same with the block's A fragments already in registers (k-step outer): for callers that load the NEXT block's fragments
+// from LDS before they multiply the current one (k_stage's K-block loop, round 4), so that no MFMA waits for an LDS read.
+template <int MT, int T>
+__device__ __forceinline__ void gemm_block_regs(const f32x4 (&a)[MT], const f32x4 (&b)[T], f32x4 (&acc)[MT][T], int nk, int r0 = 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (r >= r0 && r < nk) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int t = 0; t < T; ++t) acc[mt][t] = MFMA16(a[mt][r], b[t][r], acc[mt][t]);
+        }
 }
 
 // Remainder tiles.  When an affine has 16 m + (1..4) outputs its last 16-row tile holds at most four real rows
@@ -257,18 +274,37 @@ __device__ __forceinline__ void node_tail(const StageParams& P, WP wA2, BP b2, i
     f32x4 d4[T];      // REM: 4x4-form accumulators of the last output tile
 #pragma unroll
     for (int t = 0; t < T; ++t) d4[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // (Round 4 also measured the second affine with its A fragments alternating between two register sets, like the K-block loop
+    // of k_stage: no gain at one tile per wave (layer 7: 17.3 against 17.4 us), and at two tiles per wave the second set spills —
+    // 96 bytes of scratch at 128 VGPRs, layers 3-6 +17 %.  Not kept; the |x|^p block's fragments are requested before the power.)
     if constexpr (FS) {
 #pragma unroll
         for (int mt1 = 0; mt1 < MT1; ++mt1) {
             const uint32_t nkp = P.nk2p[mt1];
             const int nk0 = nkp & 15, nk1 = (nkp >> 4) & 15;
-            if constexpr (REM) gemm_block_rem<MT2, T>(wA2 + (mt1 * 2) * MT2 * 64, z[mt1], y, d4, nk0);
-            else gemm_block<MT2, T, true>(wA2 + (mt1 * 2) * MT2 * 64, z[mt1], y, nk0);
-            f32x4 e[T];
+            if constexpr (REM) {
+                gemm_block_rem<MT2, T>(wA2 + (mt1 * 2) * MT2 * 64, z[mt1], y, d4, nk0);
+                f32x4 e[T];
 #pragma unroll
-            for (int t = 0; t < T; ++t) e[t] = pow_abs4(z[mt1][t], ex1);
-            if constexpr (REM) gemm_block_rem<MT2, T>(wA2 + (mt1 * 2 + 1) * MT2 * 64, e, y, d4, nk1);
-            else gemm_block<MT2, T, true>(wA2 + (mt1 * 2 + 1) * MT2 * 64, e, y, nk1);
+                for (int t = 0; t < T; ++t) e[t] = pow_abs4(z[mt1][t], ex1);
+                gemm_block_rem<MT2, T>(wA2 + (mt1 * 2 + 1) * MT2 * 64, e, y, d4, nk1);
+            } else if constexpr (!HG_POW_PREFETCH) {
+                gemm_block<MT2, T, true>(wA2 + (mt1 * 2) * MT2 * 64, z[mt1], y, nk0);
+                f32x4 e[T];
+#pragma unroll
+                for (int t = 0; t < T; ++t) e[t] = pow_abs4(z[mt1][t], ex1);
+                gemm_block<MT2, T, true>(wA2 + (mt1 * 2 + 1) * MT2 * 64, e, y, nk1);
+            } else {
+                gemm_block<MT2, T, true>(wA2 + (mt1 * 2) * MT2 * 64, z[mt1], y, nk0);
+                // the |x|^p block's A fragments are requested from LDS BEFORE the power is evaluated: the transcendentals cover the read
+                f32x4 ap[MT2];
+#pragma unroll
+                for (int mt = 0; mt < MT2; ++mt) ap[mt] = (wA2 + (mt1 * 2 + 1) * MT2 * 64)[mt * 64];
+                f32x4 e[T];
+#pragma unroll
+                for (int t = 0; t < T; ++t) e[t] = pow_abs4(z[mt1][t], ex1);
+                gemm_block_regs<MT2, T>(ap, e, y, nk1);
+            }
         }
     } else
 #pragma unroll
