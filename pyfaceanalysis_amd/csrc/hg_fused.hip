@@ -601,6 +601,8 @@ __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
                 if constexpr (FS && !REM && HG_A_PINGPONG) {
                     // A fragments of block kbi + 1 are read from LDS BEFORE block kbi is multiplied, into the other of two register
                     // sets (the loop body twice, so that no set is ever copied): the MFMAs of a block wait for no LDS read
+                    // (-0.6 % per step, profiles/r04_ab_lds_prefetch.txt).  Reading the K-block table entry two blocks ahead as
+                    // well, so that the input prefetch does not wait for its LDS read either, measured 0.4 % SLOWER: not kept.
                     f32x4 a0[MT1], a1[MT1];
 #pragma unroll
                     for (int mt = 0; mt < MT1; ++mt) a0[mt] = wA1[mt * 64];
