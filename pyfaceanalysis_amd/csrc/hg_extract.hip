@@ -43,18 +43,33 @@ __device__ __forceinline__ int32_t extent_entry(const double* __restrict__ box, 
     const int m = axis ? h : w, lim = axis ? fh : fw;
     const double a = (hi - lo) / m;
     double o = lo + a * 0.5;
-    for (int k = 0; k < i; ++k) o += a;
+    // PIL's running sum, one addition per output pixel before this one (rounded one by one: no contraction, no reassociation);
+    // eight per trip, so that the loop's compare-and-branch is not what the chain waits for (the 1562-entry table of the prescale
+    // took 26.8 us with one addition per trip)
+    int k = 0;
+    for (; k + 8 <= i; k += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) o = __dadd_rn(o, a);
+    }
+    for (; k < i; ++k) o = __dadd_rn(o, a);
     const int v = o < 0.0 ? -1 : (int)o;
     return (v >= 0 && v < lim) ? v : -1;
 }
 
-__global__ void k_extent_tables(const double* __restrict__ boxes, int64_t n, int w, int h, int fw, int fh, int32_t* __restrict__ tabs) {
+struct RotCoef;
+__device__ __forceinline__ void rot_coef_store(const double* __restrict__ boxes, const double* __restrict__ angs, int64_t b, int fw, int fh, RotCoef* out);
+
+// angs != nullptr: the thread of a box's first table entry also computes the box's rotation coefficients (a launch of its own —
+// k_rot_coefs — cost the cascade 4.8 us nine times per frame; here it runs beside the other threads' addition chains)
+__global__ void k_extent_tables(const double* __restrict__ boxes, int64_t n, int w, int h, int fw, int fh, int32_t* __restrict__ tabs,
+                                const double* __restrict__ angs, RotCoef* __restrict__ rot) {
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int wh = w + h;
     if (id >= n * wh) return;
     const int64_t b = id / wh;
     const int e = (int)(id - b * wh);
     tabs[b * wh + e] = extent_entry(boxes + b * 4, e, w, h, fw, fh);
+    if (angs && e == 0) rot_coef_store(boxes, angs, b, fw, fh, rot);
 }
 
 // One workgroup per (group of output rows, box): no index divisions, the row's source line and the column table are
@@ -150,10 +165,7 @@ __device__ __forceinline__ RotCoef rot_coef_of(const double* __restrict__ boxes,
     return rc;
 }
 
-__global__ void k_rot_coefs(const double* __restrict__ boxes, const double* __restrict__ angs, int64_t n, int fw, int fh,
-                            RotCoef* __restrict__ out) {
-    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= n) return;
+__device__ __forceinline__ void rot_coef_store(const double* __restrict__ boxes, const double* __restrict__ angs, int64_t b, int fw, int fh, RotCoef* out) {
     out[b] = rot_coef_of(boxes, angs, b, fw, fh);
 }
 
@@ -312,12 +324,13 @@ int hg_patcher_extract_rotate_device(hg_patcher* p, const void* frame_dev, int f
         p->tabs.alloc((size_t)n * (out_w + out_h) * 4);
         const int64_t n_ent = n * (out_w + out_h);
         if ((n_ent + 255) / 256 > 0x7fffffffll) hg::fail(HG_ERR_ARG, "too many boxes");
-        hipLaunchKernelGGL(k_extent_tables, (unsigned)((n_ent + 255) / 256), 256, 0, st, boxes_dev, n, out_w, out_h, frame_w, frame_h,
-                           (int32_t*)p->tabs.p);
         if (delta_angs_dev) {
             if (frame_w >= 32768 || frame_h >= 32768) hg::fail(HG_ERR_ARG, "rotated windows need a frame smaller than 32768 pixels per side");
             p->rot.alloc((size_t)n * sizeof(RotCoef));
-            hipLaunchKernelGGL(k_rot_coefs, (unsigned)((n + 255) / 256), 256, 0, st, boxes_dev, delta_angs_dev, n, frame_w, frame_h, (RotCoef*)p->rot.p);
+        }
+        hipLaunchKernelGGL(k_extent_tables, (unsigned)((n_ent + 255) / 256), 256, 0, st, boxes_dev, n, out_w, out_h, frame_w, frame_h,
+                           (int32_t*)p->tabs.p, delta_angs_dev, delta_angs_dev ? (RotCoef*)p->rot.p : nullptr);
+        if (delta_angs_dev) {
             if (frame_dtype == HG_U8)
                 launch_gather_rot<uint8_t>(frame_dev, ld, frame_w, frame_h, (const int32_t*)p->tabs.p, (const RotCoef*)p->rot.p, n, out_w, out_h, out_dev,
                                            out_dtype, ldo, st);
