@@ -88,7 +88,7 @@ def test_host_pool_under_tsan(tmp_path):
 def test_host_pipeline_plain_and_under_tsan(tmp_path):
     """The host half of hg_flow_execute (hg_hostpipe.hpp: tickets, pinned ring or direct destinations, pieces, passes, the
     fall-through from exact narrowing to the caller's type, the pass planner) with a memcpy sink in the place of the GPU
-    whose copies and passes complete late: 281 seeded cases, every row's sum computed from the wire rows the sink received.
+    whose copies and passes complete late: 285 seeded cases, every row's sum computed from the wire rows the sink received.
     Once as a plain build (must pass), once under ThreadSanitizer (skipped where TSAN cannot run)."""
     srcs = [os.path.join(ROOT, "tests", "tsan_pipe_driver.cpp"), os.path.join(ROOT, "pyfaceanalysis_amd", "csrc", "hg_hostpack.cpp")]
     inc = "-I" + os.path.join(ROOT, "pyfaceanalysis_amd", "csrc")

@@ -216,6 +216,22 @@ int main() {
                (long long)longest, (long long)p4096.back());
         ++bad;
     }
-    printf("cases %d bad %d\n", cases + 1, bad);
+    // topology helpers of the pool: whatever this machine exposes, the groups partition the node's CPUs and binding does not break a region
+    {
+        const std::vector<int> cpus = hg::cpus_of_node(0);
+        const auto groups = hg::group_by_llc(cpus);
+        size_t covered = 0;
+        for (const auto& g : groups) covered += g.size();
+        if (!cpus.empty() && (groups.empty() || covered != cpus.size())) {
+            printf("topology: %zu cpus on node 0 but the cache groups cover %zu\n", cpus.size(), covered);
+            ++bad;
+        }
+        if (hg::usable_cpus() < 1) ++bad;
+        for (int node : {0, -1, 7, 0}) {      // an existing node, "anywhere", a node that (probably) does not exist, back
+            pool.bind_to_node(node);
+            bad += run_case<float>(&pool, false, 500, 64, 64, 64 * 4 * 100, -1, true, 2, 1000 + node, "after bind_to_node");
+        }
+    }
+    printf("cases %d bad %d\n", cases + 5, bad);
     return bad != 0;
 }
