@@ -483,6 +483,9 @@ void run_host_rows_impl(hg_flow* f, Replica& rep, const void* x, int x_dtype, in
         if (!res.narrow_failed) break;
         narrow = false;      // a value that is not an integer 0..255: the rest of the call travels in the caller's type
         for (int c = 0; c < NC; ++c) HG_HIP(hipStreamSynchronize(rep.copy[c]));      // pieces of the abandoned pass must not land after the new ones
+        // ... and the passes launched so far are taken home before the wide part starts: its first passes write the input buffers
+        // straight away (the pipe assumes the buffers of its first NB passes free), and those may still be read by kernels in flight
+        sink.unpack_upto((int)sink.pass_rows.size());
     }
     const float t_sub = want_trace ? trace.now() : 0.f;
     sink.unpack_upto((int)sink.pass_rows.size());
