@@ -12,7 +12,8 @@ HG_OK = 0
 HG_ERR_ARG, HG_ERR_FORMAT, HG_ERR_DIM, HG_ERR_DEVICE, HG_ERR_NOMEM, HG_ERR_STATE = -1, -2, -3, -4, -5, -6
 HG_PLAN_GENERIC, HG_PLAN_FUSED = 0, 1
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libhigsfa.so")
+# HIGSFA_LIB: another build of the same library (same-box A/B of two commits, tools/build_ref_lib.sh) — never a different backend
+_LIB_PATH = os.environ.get("HIGSFA_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libhigsfa.so")
 _lib = None
 
 

@@ -457,6 +457,9 @@ void run_host_rows_impl(hg_flow* f, Replica& rep, const void* x, int x_dtype, in
         const int64_t max_pass = pass_rows_for(row_wire);
         J.passes = passes_from_env(J.n, max_pass);
         if (J.passes.empty()) J.passes = hg::plan_passes(J.n, pass_model(f, rep, row_src, row_wire, narrow, inline_pack ? 1 : pool->size(), max_pass, direct));
+        for (int64_t pr : J.passes)      // the buffers below were sized for widest_pass rows: a wider pass would be written past them
+            if (pr > max_pass || (size_t)pr * row_wire > rep.dx[0].bytes || (size_t)pr * y_cols * ys > rep.hy_bytes)
+                hg::fail(HG_ERR_ARG, "internal: planned pass of %lld rows exceeds the pass buffers (%lld rows)", (long long)pr, (long long)max_pass);
         static const char* pk = getenv("HIGSFA_PIECE_KIB");      // experiments: "min,max" KiB of wire bytes per copy
         size_t piece_lo = (size_t)1 << 20, piece_hi = (size_t)8 << 20;
         if (pk) {

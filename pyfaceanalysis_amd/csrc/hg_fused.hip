@@ -428,7 +428,10 @@ bool build_stages(const TNode& root, std::vector<FStage>& stages, std::string& w
 #else
 #define HG_HOT(blk) (blk)
 #endif
-template <int MT1, int MT2, int T, bool STAMP = false, bool REM = false, int KBF = 0, bool FS = false>
+// PK >= 0 (only with KBF): K-block PK of every node is a slot-major packed block of the stage below (StageParams::pack_soa): its
+// two slots are loaded with two 4-byte loads per lane at a position of the code that is fixed at compile time — a run-time test
+// per K-block in the streaming loops below cost layers 3-7, which never see such a block, 5 % (profiles/r05_packed_stores.txt).
+template <int MT1, int MT2, int T, bool STAMP = false, bool REM = false, int KBF = 0, bool FS = false, int PK = -1>
 __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
     extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
     const int tid = threadIdx.x, nthr = blockDim.x;
@@ -440,7 +443,10 @@ __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
     // part-major within an XCD: the first workgroups dispatched — the oldest on their CUs, which the SIMD arbiter favours — are
     // part 0 of EVERY chunk, so every node's tiles are served by fast and slow workgroups alike (chunk-major: +0.4 % per step)
     const int cpx = (P.n_chunks + 7) >> 3;
-    const int chunk = xcd + 8 * (kq % cpx), part = kq / cpx;
+    // pair_chunks: chunks 2c and 2c + 1 hold the four siblings of one lane-major packed output block; on ONE XCD, in the same part,
+    // their partial-line stores meet in that XCD's L2 before the line is written back (otherwise in two L2s: never)
+    const int jq = kq % cpx;
+    const int chunk = P.pair_chunks ? (((xcd + 8 * (jq >> 1)) << 1) | (jq & 1)) : xcd + 8 * jq, part = kq / cpx;
     if (chunk >= P.n_chunks) return;
     const int n_begin = chunk * P.nodes_per_wg;
     const int n_end = min(n_begin + P.nodes_per_wg, P.n_nodes);
@@ -496,9 +502,13 @@ __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
             f32x4 bq[KBF][T];
 #pragma unroll
             for (int kbi = 0; kbi < KBF; ++kbi) {
-                const int sb0 = HG_HOT(__builtin_amdgcn_readfirstlane(stab[kbi].x));
+                const int2 e0 = stab[kbi];
+                const int sb0 = HG_HOT(__builtin_amdgcn_readfirstlane(e0.x));
+                if (kbi == PK) load_kblock_soa<T, true>(P, trow, sb0, __builtin_amdgcn_readfirstlane(e0.y), lane, bq[kbi]);
+                else {
 #pragma unroll
-                for (int t = 0; t < T; ++t) bq[kbi][t] = P.in[(size_t)(trow[t] + sb0) * 64 + lane];
+                    for (int t = 0; t < T; ++t) bq[kbi][t] = P.in[(size_t)(trow[t] + sb0) * 64 + lane];
+                }
             }
             for (int grp = part; grp < P.tile_groups; grp += P.tile_parts) {
                 const int tn0 = ((grp + P.tile_parts) * nw + wave) * T;
@@ -527,7 +537,7 @@ __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
                     if (STAMP) ts0 = stamp_now();
 #pragma unroll
                     for (int kbi = 0; kbi < KBF; ++kbi) {
-                        const int nkr = __builtin_amdgcn_readfirstlane(kt[kbi].y), nk = nkr & 255, r0 = nkr >> 8;
+                        const int nkr = __builtin_amdgcn_readfirstlane(kt[kbi].y), nk = nkr & 255, r0 = (nkr >> 8) & 255;
                         if constexpr (REM) gemm_block_rem<MT1, T>(wA1 + kbi * MT1 * 64, bq[kbi], z, d4, nk, r0);
                         else gemm_block<MT1, T, FS>(wA1 + kbi * MT1 * 64, bq[kbi], z, nk, r0);
                     }
@@ -538,11 +548,18 @@ __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
                     {   // next visit's blocks: next node of this group on the same tiles, or the group's first node on the next tiles
                         const bool in_group = ln + 1 < gn;
                         const int2* ktn = in_group ? kt + KBF : stab;
+                        uint32_t rw[T];
+#pragma unroll
+                        for (int t = 0; t < T; ++t) rw[t] = in_group ? trow[t] : trow_nx[t];
 #pragma unroll
                         for (int kbi = 0; kbi < KBF; ++kbi) {
-                            const int sbn = HG_HOT(__builtin_amdgcn_readfirstlane(ktn[kbi].x));
+                            const int2 en = ktn[kbi];
+                            const int sbn = HG_HOT(__builtin_amdgcn_readfirstlane(en.x));
+                            if (kbi == PK) load_kblock_soa<T, true>(P, rw, sbn, __builtin_amdgcn_readfirstlane(en.y), lane, bq[kbi]);
+                            else {
 #pragma unroll
-                            for (int t = 0; t < T; ++t) bq[kbi][t] = P.in[(size_t)((in_group ? trow[t] : trow_nx[t]) + sbn) * 64 + lane];
+                                for (int t = 0; t < T; ++t) bq[kbi][t] = P.in[(size_t)(rw[t] + sbn) * 64 + lane];
+                            }
                         }
                     }
                     if (STAMP) ts1 = stamp_now();
@@ -569,8 +586,11 @@ __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
             const int2 kb = stab[0];
             const int sb0 = HG_HOT(__builtin_amdgcn_readfirstlane(kb.x));
             nk = __builtin_amdgcn_readfirstlane(kb.y);
+            if constexpr (REM) load_kblock<T>(P, trow, sb0, nk, lane, bf);
+            else {
 #pragma unroll
-            for (int t = 0; t < T; ++t) bf[t] = P.in[(size_t)(trow[t] + sb0) * 64 + lane];
+                for (int t = 0; t < T; ++t) bf[t] = P.in[(size_t)(trow[t] + sb0) * 64 + lane];
+            }
         }
         for (int grp = part; grp < P.tile_groups; grp += P.tile_parts) {
             // rows of the tile group after this one (or this one again when it is the last)
@@ -618,7 +638,7 @@ __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
 #pragma unroll
                             for (int mt = 0; mt < MT1; ++mt) an[mt] = wA1[((kbi + 1) * MT1 + mt) * 64];
                         }
-                        gemm_block_regs<MT1, T>(ac, bf, z, nk & 255, nk >> 8);
+                        gemm_block_regs<MT1, T>(ac, bf, z, nk & 255, (nk >> 8) & 255);
 #pragma unroll
                         for (int t = 0; t < T; ++t) bf[t] = bfn[t];
                         nk = nkn;
@@ -634,10 +654,17 @@ __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
                     const int2 kbn = in_node ? kt[kbi + 1] : (ln + 1 < gn ? kt[P.kb1] : stab[0]);
                     const int sbn = HG_HOT(__builtin_amdgcn_readfirstlane(kbn.x));
                     const int nkn = __builtin_amdgcn_readfirstlane(kbn.y);
+                    if constexpr (REM) {      // (only remainder-tile stages can have slot-major packed input: plan_slot_major)
+                        uint32_t rw[T];
 #pragma unroll
-                    for (int t = 0; t < T; ++t) bfn[t] = P.in[(size_t)((in_group ? trow[t] : trow_nx[t]) + sbn) * 64 + lane];
-                    if constexpr (REM) gemm_block_rem<MT1, T>(wA1 + kbi * MT1 * 64, bf, z, d4, nk & 255, nk >> 8);
-                    else gemm_block<MT1, T, FS>(wA1 + kbi * MT1 * 64, bf, z, nk & 255, nk >> 8);
+                        for (int t = 0; t < T; ++t) rw[t] = in_group ? trow[t] : trow_nx[t];
+                        load_kblock<T>(P, rw, sbn, nkn, lane, bfn);
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < T; ++t) bfn[t] = P.in[(size_t)((in_group ? trow[t] : trow_nx[t]) + sbn) * 64 + lane];
+                    }
+                    if constexpr (REM) gemm_block_rem<MT1, T>(wA1 + kbi * MT1 * 64, bf, z, d4, nk & 255, (nk >> 8) & 255);
+                    else gemm_block<MT1, T, FS>(wA1 + kbi * MT1 * 64, bf, z, nk & 255, (nk >> 8) & 255);
 #pragma unroll
                     for (int t = 0; t < T; ++t) bf[t] = bfn[t];
                     nk = nkn;
@@ -733,13 +760,12 @@ __global__ void __launch_bounds__(256) k_stage_splitm(StageParams P, int mt1n, i
                 nks[k] = real ? ent[k].y : 0;
                 const int sb = real ? ent[k].x : ent[0].x, wk = real ? k0 + k : k0;      // (blocks beyond the node's: a harmless re-read, no MFMA)
                 a1[k] = wnode[((size_t)wk * mt1n + w) * 64];
-#pragma unroll
-                for (int t = 0; t < T; ++t) bf[k][t] = P.in[(size_t)(trow[t] + sb) * 64 + lane];
+                load_kblock<T>(P, trow, sb, real ? ent[k].y : ent[0].y, lane, bf[k]);
             }
             if (REM && rem1) {
 #pragma unroll
                 for (int k = 0; k < KB; ++k) {
-                    const int nk = nks[k] & 255, r0 = nks[k] >> 8;
+                    const int nk = nks[k] & 255, r0 = (nks[k] >> 8) & 255;
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         if (r >= r0 && r < nk) {
@@ -750,7 +776,7 @@ __global__ void __launch_bounds__(256) k_stage_splitm(StageParams P, int mt1n, i
             } else {
 #pragma unroll
                 for (int k = 0; k < KB; ++k) {
-                    const int nk = nks[k] & 255, r0 = nks[k] >> 8;      // (r0 > 0: a packed remainder block)
+                    const int nk = nks[k] & 255, r0 = (nks[k] >> 8) & 255;      // (r0 > 0: a lane-major packed remainder block)
                     if (nks[k] == 4) {      // a whole block: four k-steps, no branch between them
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
@@ -834,7 +860,7 @@ __global__ void __launch_bounds__(256) k_stage_splitm(StageParams P, int mt1n, i
             const int slot = __builtin_amdgcn_readfirstlane(P.pack_slot[node]);
 #pragma unroll
             for (int t = 0; t < T; ++t)
-                if (tile[t] < P.n_tiles) ((float*)(P.out + ((size_t)tile[t] * P.nb_out + P.pack_base + (slot >> 2)) * 64 + lane))[slot & 3] = y[t][0];
+                if (tile[t] < P.n_tiles) *packed_slot_ptr(P, tile[t], slot, lane) = y[t][0];
         } else {
 #pragma unroll
             for (int t = 0; t < T; ++t)
@@ -877,7 +903,12 @@ StageFn pick_stage_m2(int mt2, int T) {
         default: return pick_stage_t<MT1, 4>(T);
     }
 }
-StageFn pick_stage(int mt1, int mt2, int T, bool rem = false, int kbf = 0, bool fs = false) {
+StageFn pick_stage(int mt1, int mt2, int T, bool rem = false, int kbf = 0, bool fs = false, int pk = -1) {
+    if (pk >= 0) {      // slot-major packed input at K-block 1 of 3 (plan_slot_major admits exactly these shapes)
+        if (pk == 1 && kbf == 3 && T == 2 && rem && mt1 == 3 && mt2 == 3) return fs ? (StageFn)k_stage<3, 3, 2, false, true, 3, true, 1> : (StageFn)k_stage<3, 3, 2, false, true, 3, false, 1>;
+        if (pk == 1 && kbf == 3 && T == 2 && rem && mt1 == 2 && mt2 == 2) return (StageFn)k_stage<2, 2, 2, false, true, 3, false, 1>;
+        return nullptr;
+    }
     if (fs) {       // expansion (identity, |x|^p) at compile time: the shapes of the preset networks' middle layers
         if (kbf == 3 && T == 2 && rem && mt1 == 3 && mt2 == 3) return (StageFn)k_stage<3, 3, 2, false, true, 3, true>;
         if (kbf == 4 && T == 2 && !rem && mt1 == 3 && mt2 == 3) return (StageFn)k_stage<3, 3, 2, false, false, 4, true>;
@@ -918,6 +949,9 @@ struct HostStage {
     int p_max = 0, s_max = 0;   // widest first / second affine of the layer (real outputs)
     bool rem4 = false;          // last tiles of both affines in 4x4 form (k_stage REM instantiations)
     bool pack_out = false;      // output: the remainder tiles of four sibling nodes share one block (StageParams::pack_base)
+    bool pack_soa = false;      // ... stored slot-major (StageParams::pack_soa; plan_slot_major)
+    int pack_in = 0x7fffffff;   // input: source blocks from this one on are slot-major packed blocks of the stage below (StageParams::pack_in)
+    int pk_kbi = -1;            // ... and sit at this position of every node's K-block list
     std::vector<int32_t> pack_slot;
     DevBuf d_pack_slot;
     bool has_exp = false, contig4 = false, vec_ok = false;
@@ -1228,6 +1262,7 @@ public:
                << " blocks/tile";
             hs.name = os.str();
         }
+        plan_slot_major();
         fuse01_ = can_fuse01();
         if (fuse01_) {
             stages_[0].name += "  [+ stage 1 fused in the same persistent kernel when the input allows 16-byte loads]";
@@ -1335,6 +1370,8 @@ public:
                 R.nb_out = hs.nb_out;
                 R.mto = hs.mto;
                 R.pack_base = hs.pack_out ? hs.n_nodes * (hs.mto - 1) : 0;
+                R.pack_soa = hs.pack_soa ? 1 : 0;
+                R.pack_in = hs.pack_in;
                 R.pack_slot = (const int32_t*)hs.d_pack_slot.p;
                 R.a4x4 = hs.rem4 ? 1 : 0;
                 for (int fi = 0; fi < hs.nf; ++fi) {
@@ -1621,7 +1658,11 @@ public:
                 const int kbf = (T == 2 && s.mt1 == s.mt2 && (s.mt1 == 2 || s.mt1 == 3) && !opt_.no_prefetch_all)
                                     ? (s.kb1 == 4 ? 4 : (s.kb1 == 3 && s.rem4 ? 3 : 0)) : 0;
                 const bool fs = s.has_exp && s.nf == 2 && s.funcs[0].kind == E_IDENTITY && s.funcs[1].kind == E_ABS_POW && !opt_.no_fspec;
-                const double capacity = 256.0 * resident_blocks(pick_stage(s.mt1, s.mt2, T, s.rem4, kbf, fs), nw * 64, lds_probe);
+                // slot-major packed input (plan_slot_major): the whole-visit-prefetch instantiation reads it at a fixed code position; any
+                // other shape of this call (one tile per wave: small batches) takes the generic remainder-tile loop, which tests per block
+                StageFn fn = s.pk_kbi >= 0 ? (kbf == 3 ? pick_stage(s.mt1, s.mt2, T, s.rem4, kbf, fs, s.pk_kbi) : nullptr) : pick_stage(s.mt1, s.mt2, T, s.rem4, kbf, fs);
+                if (!fn) fn = pick_stage(s.mt1, s.mt2, T, s.rem4, 0, false);
+                const double capacity = 256.0 * resident_blocks(fn, nw * 64, lds_probe);
                 int tile_parts = 1;
                 double best = 1e300;
                 for (int pp = 1; pp <= tile_groups; ++pp) {
@@ -1635,12 +1676,12 @@ public:
                 P.nodes_per_group = npg;
                 P.nodes_per_wg = npg;
                 P.n_chunks = n_groups;
+                P.pair_chunks = (s.pack_out && !s.pack_soa && npg == 2 && n_groups % 16 == 0 && !getenv("HIGSFA_NO_PAIR")) ? 1 : 0;
                 P.tile_groups = tile_groups;
                 P.tile_parts = tile_parts;
                 const int64_t blocks = (int64_t)((P.n_chunks + 7) / 8) * 8 * tile_parts;
                 if (blocks > 0x7fffffffll) fail(HG_ERR_ARG, "batch too large");
                 size_t lds_bytes = (size_t)npg * s.node_blocks * 1024 + (size_t)npg * s.bias_floats * 4 + (size_t)npg * s.kb1 * 8;
-                StageFn fn = pick_stage(s.mt1, s.mt2, T, s.rem4, kbf, fs);
 #ifdef HIGSFA_DIAG
                 const bool stamp_kbf3 = s.mt1 == 3 && s.mt2 == 3 && T == 2 && s.rem4 && kbf == 3;
                 if (opt_.stamp_stage == (int)si && (stamp_kbf3 || (s.mt1 == s.mt2 && (s.mt1 == 4 || s.mt1 == 3) && T == 2 && !s.rem4 && kbf == 0))) {
@@ -2388,6 +2429,54 @@ private:
     // second affine within one load batch) whose widest one needs at most 16 waves — the 4-2-1 nodes at the top of the preset
     // networks — and whose LDS tiles fit; the last layer always qualifies on its own when it is ordinary (then the launch is
     // k_stage_splitm's work plus the row-major store).
+    // Slot-major packed blocks (StageParams::pack_soa) between a producer that packs and a consumer whose large-batch kernel is the
+    // whole-visit-prefetch instantiation with remainder tiles (k_stage<.., REM, KBF = 3, .., PK>): every node of the consumer must
+    // read exactly one packed block, at the same position of its K-block list, with at most two k-steps.  The consumer's A
+    // fragments of that block are shifted so that its k-steps come first, and the table entry carries the first slot instead of
+    // a first k-step (load_kblock_soa).  Same products in the same order as the lane-major form.  HIGSFA_NO_SOA=1: off.
+    void plan_slot_major() {
+        if (getenv("HIGSFA_NO_SOA")) return;
+        for (size_t si = 0; si + 1 < stages_.size(); ++si) {
+            HostStage& pr = stages_[si];
+            HostStage& co = stages_[si + 1];
+            if (!pr.pack_out || co.kind != 0 || !co.rem4 || co.kb1 != 3 || co.mt1 != co.mt2 || (co.mt1 != 2 && co.mt1 != 3)) continue;
+            const int base = pr.n_nodes * (pr.mto - 1);
+            int pk = -1;
+            bool ok = true;
+            for (int ni = 0; ni < co.n_nodes && ok; ++ni) {
+                int seen = 0;
+                for (int kb = 0; kb < co.kb1; ++kb) {
+                    const int src = co.kb1tab[((size_t)ni * co.kb1 + kb) * 2], y = co.kb1tab[((size_t)ni * co.kb1 + kb) * 2 + 1];
+                    if (src < base) continue;
+                    const int nk = y & 255, r0 = y >> 8;
+                    ++seen;
+                    if (nk == 0 || nk - r0 > 2 || (pk >= 0 && pk != kb)) ok = false;
+                    pk = kb;
+                }
+                if (seen != 1) ok = false;
+            }
+            if (!ok || pk != 1) continue;      // (instantiated for position 1 of 3: two children with one remainder block between their full tiles)
+            for (int ni = 0; ni < co.n_nodes; ++ni) {
+                int32_t& y = co.kb1tab[((size_t)ni * co.kb1 + pk) * 2 + 1];
+                const int nk = y & 255, r0 = y >> 8;
+                float* wnode = co.afrag.data() + (size_t)ni * co.node_blocks * 256;
+                for (int mt = 0; mt < co.mt1; ++mt) {
+                    float* blk = wnode + ((size_t)pk * co.mt1 + mt) * 256;
+                    for (int lane = 0; lane < 64; ++lane) {
+                        float v[4] = {0.f, 0.f, 0.f, 0.f};
+                        for (int r = r0; r < nk; ++r) v[r - r0] = blk[lane * 4 + r];
+                        for (int r = 0; r < 4; ++r) blk[lane * 4 + r] = v[r];
+                    }
+                }
+                y = (nk - r0) | (r0 << 16);
+            }
+            pr.pack_soa = true;
+            co.pack_in = base;
+            co.pk_kbi = pk;
+            pr.name += "  [packed blocks slot-major]";
+        }
+    }
+
     void plan_tail() {
         tail_begin_ = -1;
         if (opt_.tail_max <= 0) return;

@@ -60,7 +60,17 @@ struct StageParams {
     // nodes shares one block — node n's row values in register pack_slot[n] % 4 of block pack_base + pack_slot[n] / 4 — instead of one block each;
     // the full tiles of node n start at block n * (mto - 1).  pack_base > 0 switches it on (producer side); a consumer sees
     // it only through its K-block table (source block, first k-step, k-steps).
+    // Round 5: where the consuming stage runs the whole-visit-prefetch instantiation of k_stage (the packed block sits at a position
+    // of the node's K-block list that is known at compile time), a packed block is stored SLOT-MAJOR — float [slot][lane], slot s =
+    // 256 contiguous bytes (pack_soa) — so that a node's store of its remainder rows, one float per lane, covers two whole 128-byte
+    // lines.  In the lane-major form (float [lane][slot]) the four siblings each write 4 of every 16 bytes of all eight lines of
+    // the block and every line goes to HBM four times (profiles/r04_traffic.json: the front kernel wrote 204.5 MB for a 167.8 MB
+    // buffer).  The consumer reads such a block one register at a time, 256 contiguous bytes per load, and only the two slots it
+    // multiplies (load_kblock_soa): the other half of the block, its cousins' rows, is never fetched.
     int32_t pack_base;
+    int32_t pack_soa;             // producer side: packed blocks are written slot-major
+    int32_t pair_chunks;          // k_stage: block -> chunk map that puts chunks 2c, 2c + 1 on one XCD (lane-major packed output of two-node chunks)
+    int32_t pack_in;              // consumer side: source blocks >= pack_in of the input are slot-major packed blocks (INT32_MAX: none)
     const int32_t* pack_slot;     // [node] -> 4 * (shared block) + register: siblings under one parent of the next layer share a block
     int32_t a4x4;                 // k_stage01p: layer-1 remainder fragments are already stored in 4x4 form
     // k_stage_prod (hg_fused_prod.hip): table-driven expansion (products, clip)
@@ -239,6 +249,48 @@ __device__ __forceinline__ void gemm_block_rem(WP wp, const f32x4 (&b)[T], f32x4
         }
 }
 
+// Slot-major packed K-block (StageParams::pack_soa) for T batch tiles.  Table entry y = k-steps | first slot << 16: the block's A
+// fragments are stored with this node's k-steps FIRST (the planner shifts them), so slot0 + r is loaded into register r and the
+// multiplication runs k-steps 0 .. nk-1 like any other block.  TWO: at most two k-steps (plan-time condition of the static path).
+template <int T, bool TWO>
+__device__ __forceinline__ void load_kblock_soa(const StageParams& P, const uint32_t (&row)[T], int sb, int y, int lane, f32x4 (&b)[T]) {
+    const int s0 = y >> 16, s1 = min(s0 + 1, 3);
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const float* f = (const float*)(P.in + (size_t)(row[t] + (uint32_t)sb) * 64) + lane;
+        b[t] = f32x4{f[s0 * 64], f[s1 * 64], 0.f, 0.f};
+    }
+    if constexpr (!TWO) {
+        if ((y & 255) > 2) {
+            const int s2 = min(s0 + 2, 3), s3 = min(s0 + 3, 3);
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const float* f = (const float*)(P.in + (size_t)(row[t] + (uint32_t)sb) * 64) + lane;
+                b[t][2] = f[s2 * 64];
+                b[t][3] = f[s3 * 64];
+            }
+        }
+    }
+}
+
+// One input K-block for T batch tiles (`row`: first block of each tile's row in the input activation; sb, y: the K-block table
+// entry, wave-uniform), for kernels that learn at run time whether a block is slot-major (the small-batch and generic forms)
+template <int T>
+__device__ __forceinline__ void load_kblock(const StageParams& P, const uint32_t (&row)[T], int sb, int y, int lane, f32x4 (&b)[T]) {
+    if (sb >= P.pack_in) {
+        load_kblock_soa<T, false>(P, row, sb, y, lane, b);
+        return;
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t) b[t] = P.in[(size_t)(row[t] + (uint32_t)sb) * 64 + lane];
+}
+
+// Where a node's remainder rows (register 0 of its last output tile) go: slot `slot` of the packed blocks (StageParams::pack_base)
+__device__ __forceinline__ float* packed_slot_ptr(const StageParams& P, int tile, int slot, int lane) {
+    float* blk = (float*)(P.out + ((size_t)tile * P.nb_out + P.pack_base + (slot >> 2)) * 64);
+    return P.pack_soa ? blk + (slot & 3) * 64 + lane : blk + lane * 4 + (slot & 3);
+}
+
 // Second half of a node: expansion of the z accumulators in registers, second affine, store.
 // wA2 / b2 point at this node's A2 fragments (+lane) and bias-2 fragment; address space (LDS or
 // global) is resolved after inlining.
@@ -335,7 +387,7 @@ __device__ __forceinline__ void node_tail(const StageParams& P, WP wA2, BP b2, i
 #pragma unroll
             for (int t = 0; t < T; ++t)
                 if (tile[t] < P.n_tiles && !no_store)
-                    ((float*)(P.out + ((size_t)tile[t] * P.nb_out + P.pack_base + (slot >> 2)) * 64 + lane))[slot & 3] = y[MT2 - 1][t][0];
+                    *packed_slot_ptr(P, tile[t], slot, lane) = y[MT2 - 1][t][0];
             return;
         }
     }

@@ -397,7 +397,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(TT == 
             const int tl = st_grp * T + t;
             if (tl < P.n_tiles) {
                 Q.out[((size_t)tl * Q.nb_out + n1) * 64 + lane] = st_y0[t];
-                ((float*)(Q.out + ((size_t)tl * Q.nb_out + Q.pack_base + (pk_slot >> 2)) * 64 + lane))[pk_slot & 3] = st_y1[t];
+                *packed_slot_ptr(Q, tl, pk_slot, lane) = st_y1[t];
             }
         }
         st_grp = -1;
@@ -706,7 +706,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     float st_y1 = 0.f;
     int st_tile = -1;
     const int pk_slot = __builtin_amdgcn_readfirstlane(Q.pack_slot[n1]);
-    const uint32_t pk_off = (uint32_t)(Q.pack_base + (pk_slot >> 2)) * 1024u + (uint32_t)(pk_slot & 3) * 4u;
+    // lane-major packed block: float [lane][slot]; slot-major (StageParams::pack_soa): float [slot][lane]
+    const uint32_t pk_off = (uint32_t)(Q.pack_base + (pk_slot >> 2)) * 1024u + (uint32_t)(pk_slot & 3) * (Q.pack_soa ? 256u : 4u);
+    const uint32_t pk_lane = (uint32_t)lane * (Q.pack_soa ? 4u : 16u);
     const uint32_t out_tile_bytes = (uint32_t)Q.nb_out * 1024u;
     auto flush = [&]() {
         if (st_tile < 0) return;
@@ -715,7 +717,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
 #endif
         const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(Q.out + (size_t)st_tile * Q.nb_out * 64), 0, (int)out_tile_bytes, kBufferFlags);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, st_y0), r, (uint32_t)lane * 16u, (uint32_t)n1 * 1024u, 0);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(st_y1), r, (uint32_t)lane * 16u, pk_off, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(st_y1), r, pk_lane, pk_off, 0);
         st_tile = -1;
     };
     unsigned long long t_top = 0, t_l0 = 0, t_l1 = 0, t_all0 = 0, rt0 = 0, ts = 0;

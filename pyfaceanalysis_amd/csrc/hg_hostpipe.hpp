@@ -53,21 +53,27 @@ struct PassModel {
 inline std::vector<int64_t> plan_passes(int64_t n, const PassModel& m) {
     std::vector<int64_t> out;
     if (n <= 0) return out;
-    const int64_t unit = 16 * std::max<int64_t>(1, (n + 16 * 512 - 1) / (16 * 512));
+    // No pass may exceed max_pass_rows: the caller sizes its device and pinned buffers for exactly that many rows.  The unit grows
+    // with n only while it stays below that bound (round 4 let it grow past it: a call of more wire bytes than ~8 GiB planned
+    // passes wider than their buffers — ADVICE r4); for long calls with a small bound the table simply has more entries.
+    const int64_t cap = std::max<int64_t>(1, m.max_pass_rows);
+    int64_t unit = 16 * std::max<int64_t>(1, (n + 16 * 512 - 1) / (16 * 512));
+    if (unit > cap) unit = cap >= 16 ? cap / 16 * 16 : cap;
     const int64_t U = (n + unit - 1) / unit;
-    const int64_t span = std::max<int64_t>(1, std::min<int64_t>(64, m.max_pass_rows / unit));
+    const int64_t span = std::max<int64_t>(1, std::min<int64_t>(64, cap / unit));
     auto rows = [&](int64_t i) { return std::min(i * unit, n); };
     std::vector<double> fin((size_t)U + 1, 0.0);
-    std::vector<int32_t> from((size_t)U + 1, 0), cnt((size_t)U + 1, 0);
+    std::vector<int32_t> cnt((size_t)U + 1, 0);
+    std::vector<int64_t> from((size_t)U + 1, 0);
     for (int64_t i = 1; i <= U; ++i) {
         const double arr = m.lat_us + m.arrive_us_per_row * (double)rows(i);
         double best = std::numeric_limits<double>::infinity();
-        int32_t bj = (int32_t)(i - 1);
+        int64_t bj = i - 1;
         for (int64_t j = std::max<int64_t>(0, i - span); j < i; ++j) {
             const double t = std::max(fin[(size_t)j], arr) + m.c0_us + m.c1_us_per_row * (double)(rows(i) - rows(j)) + m.per_pass_us * (cnt[(size_t)j] + 1);
             if (t < best - 1e-9) {      // ties: the earlier j (the longer pass) wins
                 best = t;
-                bj = (int32_t)j;
+                bj = j;
             }
         }
         from[(size_t)i] = bj;
@@ -76,6 +82,8 @@ inline std::vector<int64_t> plan_passes(int64_t n, const PassModel& m) {
     }
     for (int64_t i = U; i > 0; i = from[(size_t)i]) out.push_back(rows(i) - rows(from[(size_t)i]));
     std::reverse(out.begin(), out.end());
+    for (int64_t p : out)
+        if (p <= 0 || p > cap) throw std::logic_error("plan_passes: a pass outside 1..max_pass_rows");
     return out;
 }
 

@@ -157,9 +157,9 @@ public:
     // max_workers: only workers 0 .. max_workers-1 take tickets (rows that are only copied into device memory are bound by the
     // link, which four to six writers fill; more of them only add contention)
     void begin(int n_tasks, const std::function<void(int)>& fn, int max_workers = 1 << 30) {
-        region_.lock();
-        auto job = std::make_shared<Job>(&fn, n_tasks);
+        auto job = std::make_shared<Job>(&fn, n_tasks);      // allocated BEFORE the region lock: a bad_alloc must not leave it held
         job->cap = std::max(1, max_workers);
+        region_.lock();
         cur_ = job;
         {
             std::lock_guard<std::mutex> lk(m_);

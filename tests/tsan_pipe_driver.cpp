@@ -145,7 +145,7 @@ static int run_case(hg::HostPool* pool, bool inline_pack, int64_t n, int64_t in_
         int64_t sum = 0;
         for (auto p : J.passes) {
             sum += p;
-            if (p <= 0 || p > std::max<int64_t>(M.max_pass_rows, 16 * ((J.n + 16 * 512 - 1) / (16 * 512)))) { printf("%s: bad pass size %lld\n", what, (long long)p); return 1; }
+            if (p <= 0 || p > M.max_pass_rows) { printf("%s: bad pass size %lld\n", what, (long long)p); return 1; }
         }
         if (sum != J.n) { printf("%s: plan covers %lld of %lld rows\n", what, (long long)sum, (long long)J.n); return 1; }
         J.piece_min = 1 + (int64_t)(rng() % 40);
@@ -157,7 +157,7 @@ static int run_case(hg::HostPool* pool, bool inline_pack, int64_t n, int64_t in_
         sink.pending.clear();
         sink.marks.clear();
         if (direct_slots) {
-            sink.slots.assign((size_t)direct_slots, std::vector<uint8_t>((size_t)std::max<int64_t>(M.max_pass_rows, 16 * ((J.n + 16 * 512 - 1) / (16 * 512))) * in_dim * sizeof(T) + 64));
+            sink.slots.assign((size_t)direct_slots, std::vector<uint8_t>((size_t)M.max_pass_rows * in_dim * sizeof(T) + 64));
             sink.finished_upto = 0;
             sink.slot_off = (seed % 3) * 16;
             J.direct_slots = direct_slots;
@@ -215,6 +215,28 @@ int main() {
         printf("planner: unexpected shape (%zu passes for 728 rows, %zu for 4096, longest %lld, last %lld)\n", p728.size(), p4096.size(),
                (long long)longest, (long long)p4096.back());
         ++bad;
+    }
+    // planner bound: whatever the call's length, no pass is wider than max_pass_rows — the device and pinned buffers
+    // of a call are sized for exactly that many rows — and the passes cover the call
+    {
+        const int64_t ns[] = {1, 15, 16, 17, 4096, 8191, 8192, 8193, 9000, 65536, 70000, 140000, 1000003, 5000000};
+        const int64_t caps[] = {1, 7, 16, 17, 100, 128, 144, 256, 1024, 65536};
+        for (int64_t n : ns)
+            for (int64_t cap : caps) {
+                hg::PassModel Q;
+                Q.max_pass_rows = cap;
+                const auto ps = hg::plan_passes(n, Q);
+                int64_t sum = 0, widest = 0;
+                for (auto p : ps) {
+                    sum += p;
+                    widest = std::max(widest, p);
+                    if (p <= 0) widest = cap + 1;
+                }
+                if (sum != n || widest > cap) {
+                    printf("planner: n %lld max_pass_rows %lld -> %zu passes, sum %lld, widest %lld\n", (long long)n, (long long)cap, ps.size(), (long long)sum, (long long)widest);
+                    ++bad;
+                }
+            }
     }
     // topology helpers of the pool: whatever this machine exposes, the groups partition the node's CPUs and binding does not break a region
     {

@@ -5,6 +5,16 @@
 #include <vector>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 0, 0, 0)
+// lane-group reduce-scatter of a 4x4-form accumulator (hg_fused_dev.hpp rem4_total)
+__device__ __forceinline__ float rem4_total(f32x4 d) {
+    const auto p = __builtin_amdgcn_permlane16_swap(__float_as_uint(d[0]), __float_as_uint(d[1]), false, false);
+    const float t = __uint_as_float(p[0]) + __uint_as_float(p[1]);
+    const auto q = __builtin_amdgcn_permlane16_swap(__float_as_uint(d[2]), __float_as_uint(d[3]), false, false);
+    const float u = __uint_as_float(q[0]) + __uint_as_float(q[1]);
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(t), __float_as_uint(u), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 
 // MT = 4 m-tiles, T = 2 batch tiles -> 8 accumulators, 32 MFMAs per "K-block" iteration
 template <int V>
@@ -19,6 +29,8 @@ __global__ void __launch_bounds__(512) k(const f32x4* __restrict__ w, const int2
     for (int m = 0; m < 4; ++m) for (int t = 0; t < 2; ++t) acc[m][t] = f32x4{0, 0, 0, 0};
     f32x4 bf[2] = {w[lane], w[64 + lane]};
     f32x4 a[4], an[4];
+    f32x4 d4[3][2];
+    for (int q = 0; q < 3; ++q) for (int t = 0; t < 2; ++t) d4[q][t] = f32x4{0, 0, 0, 0};
     const f32x4* wl = smem + lane;
     if (V == 2) for (int m = 0; m < 4; ++m) a[m] = wl[m * 64];
     int nk = nk_in;
@@ -35,6 +47,41 @@ __global__ void __launch_bounds__(512) k(const f32x4* __restrict__ w, const int2
         } else if (V == 2) {
             const int kn = (it + 1) & 15;
             for (int m = 0; m < 4; ++m) an[m] = wl[(kn * 4 + m) * 64];
+        }
+        if (V == 6 || V == 7) {
+            // Round 5: a 60-row affine as 3 full m-tiles on the 16x16x4 form + its 12-row tail as three 4-row
+            // groups on v_mfma_f32_4x4x1 (8 cycles each instead of a fourth 32-cycle tile), the tail's A values read from a compact
+            // LDS image (16 distinct 16-byte words per group: lanes with the same (g, i) read the same word) and the three
+            // reduce-scatters every `visit` K-blocks (V6; V7 leaves them out to price them).  Same "useful" rows as V4.
+            int2 e = st[kb];
+            nk = __builtin_amdgcn_readfirstlane(e.y);
+            for (int m = 0; m < 3; ++m) a[m] = wl[(kb * 4 + m) * 64];
+            f32x4 a4[3];
+            const f32x4* w4 = smem + (kb * 4 + 3) * 64 + ((lane >> 4) * 4 + (lane & 3));
+            for (int q = 0; q < 3; ++q) a4[q] = w4[q * 16];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (r >= nk) continue;
+#pragma unroll
+                for (int m = 0; m < 3; ++m)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) acc[m][t] = MFMA16(a[m][r], bf[t][r], acc[m][t]);
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) d4[q][t] = MFMA4(a4[q][r], bf[t][r], d4[q][t]);
+            }
+            if (V == 6 && (it % 12) == 11) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        acc[3][t][q] += rem4_total(d4[q][t]);
+                        d4[q][t] = f32x4{0, 0, 0, 0};
+                    }
+                }
+            }
+            continue;
         }
         if (V == 5) {      // the order gemm_block used until round 2: m-tile outer (one A fragment live), k-step inner
             int2 e = st[kb];
@@ -63,6 +110,7 @@ __global__ void __launch_bounds__(512) k(const f32x4* __restrict__ w, const int2
     }
     f32x4 s = f32x4{0, 0, 0, 0};
     for (int m = 0; m < 4; ++m) for (int t = 0; t < 2; ++t) s += acc[m][t];
+    for (int q = 0; q < 3; ++q) for (int t = 0; t < 2; ++t) s += d4[q][t];
     out[(size_t)blockIdx.x * blockDim.x + tid] = s[0] + s[1] + s[2] + s[3];
 }
 
@@ -100,6 +148,8 @@ int main(int argc, char** argv) {
         run<3>("V3 V1 + nk branches", w, tab, out, thr, per);
         run<4>("V4 V3 + LDS table/readfirstlane", w, tab, out, thr, per);
         run<5>("V5 V4 with m-tile outer, k-step inner", w, tab, out, thr, per);
+        run<6>("V6 V4, 12-row tail as 3 x 4x4x1 + reduce", w, tab, out, thr, per);
+        run<7>("V7 V6 without the reduce-scatters", w, tab, out, thr, per);
     }
     return 0;
 }
