@@ -157,11 +157,11 @@ def _frame_leg(flow, dev, reps, flow_factory):
     dc = DeviceCascade(stages, (SIDE, SIDE), N_COLS, pipe)
     win = (boxes, level)
     for _ in range(40):      # ~60 ms of frames before the timed ones: the chip has idled through the calibration above
-        out = dc.detect(dc.prescale(frame), smallest_face=0.1, windows=win)
+        out = dc.detect_frame(frame, smallest_face=0.1)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(reps):
-        out = dc.detect(dc.prescale(frame), smallest_face=0.1, windows=win)
+        out = dc.detect_frame(frame, smallest_face=0.1)
     torch.cuda.synchronize(dev)
     per_frame = (time.perf_counter() - t0) / reps
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -190,7 +190,7 @@ def _frame_leg(flow, dev, reps, flow_factory):
             torch.cuda.set_device(dev)
             with torch.cuda.stream(streams[i]):
                 for _ in range(k):
-                    outs[i] = cascades[i].detect(cascades[i].prescale(frame), smallest_face=0.1, windows=win)
+                    outs[i] = cascades[i].detect_frame(frame, smallest_face=0.1)
             streams[i].synchronize()
 
         def run_group(n_par, k):

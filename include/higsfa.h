@@ -142,6 +142,11 @@ int hg_stream_wait_event(void* stream, void* ev);
  * Lets the host skip a wait that would only put a barrier packet in front of the next launch (measured: 4.5 us). */
 int hg_event_query(void* ev);
 
+/* How the last hg_flow_execute of this handle moved the caller's rows (FaceDetectUpdated.py:699 hands over a host ndarray,
+ * face_analysis.py:786): *transport = 1 — packer threads stored the wire rows straight into device memory, which is done only
+ * where the device reports a large BAR AND hsa_amd_pointer_info confirms every input buffer host-mapped at its device address;
+ * 0 — pinned ring + copy queues (HIGSFA_HOST_DIRECT=0, or any other answer of the probe); -1 — no such call yet. */
+int hg_flow_host_transport(const hg_flow* f, int* transport);
 /* Per-stage timing (the `benchmark=` kwarg of the reference call; benchmarking.py:39-58).
  * When enabled every stage launch is bracketed by hipEvents on the execution stream. */
 int hg_flow_set_profiling(hg_flow* f, int enabled);
@@ -165,6 +170,11 @@ void hg_gauss_free(hg_gauss* g);
  * device float64 arrays of n elements (out_std may be null).  Enqueued on `stream`. */
 int hg_gauss_regression_device(hg_gauss* g, const void* x_dev, int x_dtype, int64_t n, int64_t ldx,
                                double* out_reg_dev, double* out_std_dev, void* stream);
+/* m <= 4 classifiers on the SAME feature rows in one launch — a cascade stage that owns a network and the stages behind it whose
+ * network is None reuse one sl (FaceDetectUpdated.py:678-682, :704-706; Pipelines/Pipeline_experimental.txt:8-19): regressions of
+ * classifier s go to out_reg_dev[s * out_stride + row].  Same bits as m calls of hg_gauss_regression_device. */
+int hg_gauss_regression_multi_device(hg_gauss* const* gs, int m, const void* x_dev, int x_dtype, int64_t n, int64_t ldx,
+                                     double* out_reg_dev, int64_t out_stride, void* stream);
 /* Host-buffer convenience wrapper (synchronous). */
 int hg_gauss_regression(hg_gauss* g, const void* x, int x_dtype, int64_t n, int64_t ldx,
                         double* out_reg, double* out_std);
@@ -229,7 +239,10 @@ int hg_gather_rows_device(int device, const void* src_dev, void* dst_dev, int64_
 /* The whole stage loop (FaceDetectUpdated.py:665-766) of one batch of first-stage windows as ONE host call: for every stage
  * extract (rotated by -angle, unless the previous stage was a Disc stage or the stage has no network, :674-681) -> the stage's
  * flow (hg_flow_execute_device; NULL = reuse the previous features, the pipeline's "None0") -> regression -> coordinate update,
- * discard test, compaction (one fused kernel).  No per-candidate array visits the host; the host reads the survivor count only
+ * discard test, compaction (one fused kernel).  A stage that owns a network and the stages behind it whose network is NULL (at most
+ * four) read the same sl: they run as ONE regression launch (hg_gauss_regression_multi_device) and ONE glue launch that applies
+ * their updates and discard tests per row in stage order — same survivors, same order, same bits (HIGSFA_CASCADE_NO_GROUPS=1:
+ * one stage per launch).  No per-candidate array visits the host; the host reads the survivor count only
  * after Disc stages (where it shrinks a lot and sizes the next launches) — between them launches are sized by the last count
  * read and the kernels take the exact count from device memory.  All pyramid levels may be one batch (:599).
  * flow / classifier handles stay owned by the caller and must live on `device`. */
@@ -253,6 +266,30 @@ int hg_cascade_detect_device(hg_cascade* c, const void* frame_dev, int frame_h, 
                              const double* boxes_host, const double* level_host, int64_t n0, double* out_coords,
                              double* out_angles, int32_t* out_orig_index, double* out_confidence, int64_t out_cap,
                              int64_t* n_out, int32_t* stage_counts, int64_t* rows_executed, void* stream);
+
+/* The same with the first-stage windows computed ON THE DEVICE from the grid's closed form (face_analysis.py:630-646, :661-669):
+ * pyramid level L holds ny x nx windows, y-major, at numpy.linspace(0, stop, n) positions; a window is
+ * (posX, posY, posX + patch_w - 1, posY + patch_h - 1); every window of the level carries (max_dx, max_dy, base_side)
+ * (face_analysis.py:651-652, FaceDetectUpdated.py:604-605).  float64 in numpy's operation order: the boxes equal the host
+ * formulas' bit for bit (hg_cascade_grid_device writes them to device arrays for inspection; boxes_dev == NULL: only *n0). */
+typedef struct hg_cascade_level {
+    int32_t nx, ny;                      /* grid points along x / y (face_analysis.py:640-641)            */
+    double x_stop, y_stop;               /* im_width - patch_w, im_height - patch_h (end points, :645-646) */
+    double patch_w, patch_h;             /* subimage size x sampling value (:630-631)                      */
+    double max_dx, max_dy, base_side;    /* net_Dx * patch_w / regression_width, ..., sqrt(pw^2 + ph^2)    */
+} hg_cascade_level;
+int hg_cascade_detect_levels_device(hg_cascade* c, const void* frame_dev, int frame_h, int frame_w, int64_t ld,
+                                    const hg_cascade_level* levels, int n_levels, double* out_coords, double* out_angles,
+                                    int32_t* out_orig_index, double* out_confidence, int64_t out_cap, int64_t* n_out,
+                                    int32_t* stage_counts, int64_t* rows_executed, void* stream);
+/* One frame, one host call: the reference's prescale (im.resize((w, h), NEAREST), FaceDetectUpdated.py:551-561; prescale_w = 0: none)
+ * into a buffer owned by the cascade, the grid of the PRESCALED frame from `levels`, the stage loop. */
+int hg_cascade_detect_frame_device(hg_cascade* c, const void* frame_dev, int frame_h, int frame_w, int64_t ld, int prescale_w,
+                                   int prescale_h, const hg_cascade_level* levels, int n_levels, double* out_coords,
+                                   double* out_angles, int32_t* out_orig_index, double* out_confidence, int64_t out_cap,
+                                   int64_t* n_out, int32_t* stage_counts, int64_t* rows_executed, void* stream);
+int hg_cascade_grid_device(int device, const hg_cascade_level* levels, int n_levels, double* boxes_dev, double* level_dev,
+                           int64_t cap, int64_t* n0, void* stream);
 
 /* --- SFA training step for one layer of nodes (BASELINE.json configs[4]) -----
  * Not on the reference's path (it never trains, face_analysis.py:451-479); restates

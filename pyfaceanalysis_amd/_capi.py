@@ -30,6 +30,10 @@ class HgCascadeConsts(C.Structure):
         "tolerance_angle_deviation", "max_scale_radio", "min_scale_radio", "net_Dang", "cut_off_face")]
 
 
+class HgCascadeLevel(C.Structure):      # hg_cascade_level: one pyramid level of the first-stage grid (face_analysis.py:630-652)
+    _fields_ = [("nx", C.c_int32), ("ny", C.c_int32)] + [(n, C.c_double) for n in ("x_stop", "y_stop", "patch_w", "patch_h", "max_dx", "max_dy", "base_side")]
+
+
 class HgCascadeStage(C.Structure):
     _fields_ = [("type", C.c_int32), ("serial", C.c_int32), ("flow", C.c_void_p), ("classifier", C.c_void_p)]
 
@@ -81,6 +85,7 @@ def lib():
         "hg_event_record": (C.c_int, [vp, vp]),
         "hg_stream_wait_event": (C.c_int, [vp, vp]),
         "hg_event_query": (C.c_int, [vp]),
+        "hg_flow_host_transport": (C.c_int, [vp, C.POINTER(C.c_int)]),
         "hg_flow_set_profiling": (C.c_int, [vp, i32]),
         "hg_flow_stage_times": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(i64), i32, C.POINTER(i32)]),
         "hg_flow_stage_name": (C.c_int, [vp, i32, C.c_char_p, sz]),
@@ -89,6 +94,7 @@ def lib():
         "hg_gauss_free": (None, [vp]),
         "hg_gauss_regression_device": (C.c_int, [vp, vp, i32, i64, i64, vp, vp, vp]),
         "hg_gauss_regression": (C.c_int, [vp, vp, i32, i64, i64, vp, vp]),
+        "hg_gauss_regression_multi_device": (C.c_int, [C.POINTER(vp), i32, vp, i32, i64, i64, vp, i64, vp]),
         "hg_patcher_create": (C.c_int, [i32, C.POINTER(vp)]),
         "hg_patcher_free": (None, [vp]),
         "hg_patcher_extract_device": (C.c_int, [vp, vp, i32, i32, i32, i64, vp, i64, i32, i32, vp, i32, i64, vp]),
@@ -101,6 +107,9 @@ def lib():
         "hg_cascade_create": (C.c_int, [C.POINTER(HgCascadeStage), i32, i32, i32, i32, C.POINTER(HgCascadeConsts), vp, i32, i32, C.POINTER(vp)]),
         "hg_cascade_free": (None, [vp]),
         "hg_cascade_detect_device": (C.c_int, [vp, vp, i32, i32, i64, vp, vp, i64, vp, vp, vp, vp, i64, C.POINTER(i64), vp, C.POINTER(i64), vp]),
+        "hg_cascade_detect_levels_device": (C.c_int, [vp, vp, i32, i32, i64, C.POINTER(HgCascadeLevel), i32, vp, vp, vp, vp, i64, C.POINTER(i64), vp, C.POINTER(i64), vp]),
+        "hg_cascade_detect_frame_device": (C.c_int, [vp, vp, i32, i32, i64, i32, i32, C.POINTER(HgCascadeLevel), i32, vp, vp, vp, vp, i64, C.POINTER(i64), vp, C.POINTER(i64), vp]),
+        "hg_cascade_grid_device": (C.c_int, [i32, C.POINTER(HgCascadeLevel), i32, vp, vp, i64, C.POINTER(i64), vp]),
         "hg_sfa_train_layer": (C.c_int, [vp, i32, i32, i64, i64, vp, C.c_int32, C.c_int32, i32, vp, vp, vp, vp]),
         "hg_pca_train_layer": (C.c_int, [vp, i32, i32, i64, i64, vp, C.c_int32, C.c_int32, i32, vp, vp, vp, vp]),
         "hg_train_apply_device": (C.c_int, [vp, i32, i64, i64, vp, C.c_int32, C.c_int32, vp, vp, C.c_int32, C.c_int32, vp, vp, vp, i64, i32]),
@@ -116,11 +125,12 @@ def lib():
 EXPORTED_SYMBOLS = (
     "hg_version", "hg_last_error", "hg_device_count", "hg_flow_load", "hg_flow_free", "hg_flow_info",
     "hg_flow_describe", "hg_flow_to_device", "hg_flow_reserve", "hg_flow_execute", "hg_flow_execute_sharded",
-    "hg_flow_execute_device", "hg_event_create", "hg_event_create_on", "hg_event_destroy", "hg_event_record", "hg_stream_wait_event", "hg_event_query", "hg_flow_set_profiling", "hg_flow_stage_times", "hg_flow_stage_name",
+    "hg_flow_execute_device", "hg_event_create", "hg_event_create_on", "hg_event_destroy", "hg_event_record", "hg_stream_wait_event", "hg_event_query", "hg_flow_host_transport", "hg_flow_set_profiling", "hg_flow_stage_times", "hg_flow_stage_name",
     "hg_flow_reset_profile", "hg_gauss_create", "hg_gauss_free", "hg_gauss_regression_device",
     "hg_gauss_regression", "hg_patcher_create", "hg_patcher_free", "hg_patcher_extract_device",
     "hg_patcher_extract", "hg_patcher_extract_rotate_device", "hg_patcher_extract_rotate", "hg_cascade_update_device",
     "hg_cascade_compact_device", "hg_gather_rows_device", "hg_cascade_create", "hg_cascade_free", "hg_cascade_detect_device",
+    "hg_cascade_detect_levels_device", "hg_cascade_detect_frame_device", "hg_cascade_grid_device", "hg_gauss_regression_multi_device",
     "hg_sfa_train_layer", "hg_pca_train_layer", "hg_train_apply_device",
 )
 

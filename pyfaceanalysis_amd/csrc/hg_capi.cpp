@@ -4,12 +4,16 @@
 #include <cctype>
 #include <chrono>
 #include <condition_variable>
+#include <cstring>
 #include <functional>
 #include <mutex>
 #include <thread>
 
+#include <dlfcn.h>
 #include <sys/syscall.h>
 #include <unistd.h>
+
+#include <hsa/hsa_ext_amd.h>      // types only: hsa_amd_pointer_info is looked up in the runtime the process already has
 
 #include "hg_common.hpp"
 #include "hg_hostpipe.hpp"
@@ -71,6 +75,34 @@ int node_of_device(int device) {
     return node;
 }
 
+// May the HOST store into this device allocation?  hipDeviceAttributeIsLargeBar says what the device can do, not what THIS
+// allocation is: the documented answer is hsa_amd_pointer_info — `hostBaseAddress`, "base address at which the host agent may access
+// the allocation" (hsa_ext_amd.h) — which must be non-null and, because the packers store through the device pointer's own value,
+// equal to the address the device uses; the range written must lie inside the allocation.  The function is taken from the HSA
+// runtime that is ALREADY in the process (the one HIP runs on; RTLD_NOLOAD: never a second copy); without it, or with any answer
+// but a clear yes, the call falls back to the pinned ring and the copy queues — never discovered by faulting.
+// HIGSFA_HOST_PROBE_DENY=1 (read per probe; tests) forces the "not mappable" answer.
+bool host_can_store(const void* p, size_t bytes) {
+    typedef hsa_status_t (*info_fn)(const void*, hsa_amd_pointer_info_t*, void* (*)(size_t), uint32_t*, hsa_agent_t**);
+    static const info_fn fn = [] {
+        info_fn f = nullptr;
+        for (const char* name : {"libhsa-runtime64.so.1", "libhsa-runtime64.so"})
+            if (void* h = dlopen(name, RTLD_NOLOAD | RTLD_NOW)) {
+                f = (info_fn)dlsym(h, "hsa_amd_pointer_info");
+                if (f) break;
+            }
+        return f;
+    }();
+    if (!fn || !p || getenv("HIGSFA_HOST_PROBE_DENY")) return false;
+    hsa_amd_pointer_info_t info;
+    memset(&info, 0, sizeof info);
+    info.size = sizeof info;
+    if (fn(p, &info, nullptr, nullptr, nullptr) != HSA_STATUS_SUCCESS) return false;
+    if (info.type != HSA_EXT_POINTER_TYPE_HSA || !info.hostBaseAddress || info.hostBaseAddress != info.agentBaseAddress) return false;
+    const char *base = (const char*)info.agentBaseAddress, *q = (const char*)p;
+    return q >= base && q + bytes <= base + info.sizeInBytes;
+}
+
 // One execution context: the executor on one device with its streams and staging buffers.
 struct Replica {
     int device = -1;
@@ -85,6 +117,23 @@ struct Replica {
     hipEvent_t mk_ev[MK] = {};             // created on first use
     std::unique_ptr<HostPool> pool;        // shard replicas pack with a few threads of their own; null: the process-wide pool
     bool large_bar = false;                // the host can store into this device's memory (hipDeviceAttributeIsLargeBar)
+    const void* dx_probed[NB] = {};        // host_can_store() asked about dx[b] at this address / size ...
+    size_t dx_probed_bytes[NB] = {};
+    bool dx_host_ok[NB] = {};              // ... and answered this
+    int last_transport = -1;               // of the last host-rows call: 0 pinned ring + copy queues, 1 direct stores (hg_flow_host_transport)
+    // every input buffer of the rotation confirmed host-writable (asked once per allocation)
+    bool inputs_host_writable() {
+        bool ok = true;
+        for (int b = 0; b < NB; ++b) {
+            if (dx_probed[b] != dx[b].p || dx_probed_bytes[b] != dx[b].bytes) {
+                dx_host_ok[b] = host_can_store(dx[b].p, dx[b].bytes);
+                dx_probed[b] = dx[b].p;
+                dx_probed_bytes[b] = dx[b].bytes;
+            }
+            ok = ok && dx_host_ok[b];
+        }
+        return ok;
+    }
 
     void create(int dev) {
         HG_HIP(hipSetDevice(dev));
@@ -420,13 +469,15 @@ void run_host_rows_impl(hg_flow* f, Replica& rep, const void* x, int x_dtype, in
     // tools/ubench/bar_write_bw.cpp: 42 - 44 GB/s from four or more threads of either socket, a kernel launched afterwards sees
     // the bytes also in a buffer an earlier kernel has read — and there is no pinned ring and no copy queue: in the staged form
     // the DMA engine ran at 25 - 45 GB/s beside the packers' memory traffic and trailed them by up to 0.4 ms at the end of a call.
-    const bool direct = rep.large_bar && f->direct;
-    const size_t ring_want = direct ? 0 : std::max<size_t>(64 * row_given, std::min<size_t>((size_t)64 << 20, (size_t)n * row_given));
-    rep.need_streams();
-    rep.need_pinned(ring_want, (size_t)widest_pass * y_cols * ys);
+    // ... and only into buffers that the runtime confirms are mapped for the host at the device's own address (host_can_store)
     for (int b = 0; b < NB; ++b) {
         rep.dx[b].alloc(std::min<size_t>(pass_bytes, (size_t)((n + 15) / 16 * 16) * row_given));
     }
+    const bool direct = rep.large_bar && f->direct && rep.inputs_host_writable();
+    rep.last_transport = direct ? 1 : 0;
+    const size_t ring_want = direct ? 0 : std::max<size_t>(64 * row_given, std::min<size_t>((size_t)64 << 20, (size_t)n * row_given));
+    rep.need_streams();
+    rep.need_pinned(ring_want, (size_t)widest_pass * y_cols * ys);
     rep.exec->reserve(widest_pass);
 
     HostPool* pool = rep.pool ? rep.pool.get() : &HostPool::get();
@@ -500,7 +551,7 @@ void run_host_rows_impl(hg_flow* f, Replica& rep, const void* x, int x_dtype, in
             if (t >= 0) pack_first = std::min(pack_first, t);
         }
         fprintf(stderr, "[host trace] memory nodes: caller rows %d, pinned ring %d, device %d; packers %d; %s\n", node_of_address(x), rep.ring ? node_of_address(rep.ring) : -1,
-                node_of_device(rep.device), pool->size(), direct ? "direct stores into device memory" : "pinned ring + copy queues");
+                node_of_device(rep.device), pool->size(), direct ? "direct stores into device memory (hsa_amd_pointer_info: host-mapped)" : "pinned ring + copy queues");
         fprintf(stderr, "[host trace] n %lld dtype %d: %zu tickets, first done %.0f us, last done %.0f us; submitted %.0f us; call %.0f us\n", (long long)n, x_dtype,
                 trace.ticket_done.size(), pack_first, pack_end, t_sub, trace.now());
         size_t pi = 0;
@@ -782,6 +833,13 @@ int hg_event_query(void* ev) {
         else HG_HIP(e);
     });
     return rc == HG_OK ? done : rc;
+}
+
+int hg_flow_host_transport(const hg_flow* f, int* transport) {
+    return guarded([&] {
+        if (!f || !transport) hg::fail(HG_ERR_ARG, "null argument");
+        *transport = f->main.last_transport;
+    });
 }
 
 int hg_flow_set_profiling(hg_flow* f, int enabled) {

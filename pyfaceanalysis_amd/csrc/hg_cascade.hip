@@ -15,6 +15,7 @@
 #include <cstring>
 
 #include "hg_common.hpp"
+#include "hg_gauss_dev.hpp"
 
 namespace hg { void set_last_error(const std::string& s); }
 
@@ -221,26 +222,116 @@ __global__ void k_cascade_init(int n, const double* __restrict__ orig_coords, do
     oidx[i] = i;
 }
 
-// The body for ONE workgroup of any size up to 1024 threads (k_cascade_stage: 1024; the last workgroup of k_cascade_stage_reg: 256).
-__device__ __forceinline__ void cascade_stage_body(int type, const hg_cascade_consts& c, const StageArrays& A, int32_t* host_count, int seq, const HostResults& H) {
+// The same start with the windows computed HERE from the grid's closed form (round 5; the boxes and level constants of a 1080p
+// frame were 97 KB of pageable host memory copied per frame): level L holds ny x nx windows, y-major, at
+// numpy.linspace(0, stop, n) positions — i * (stop / (n - 1)), the last one `stop` itself, a single one 0.0 — and a window is
+// (posX, posY, posX + pw - 1, posY + ph - 1)  (face_analysis.py:630-646, :661-669; grid.level_boxes).  float64 in numpy's
+// operation order, no contraction: the boxes equal the host's bit for bit (tests/test_cascade.py).
+constexpr int kMaxLevels = 32;
+struct LevelTable {
+    int32_t n_levels, pad;
+    int32_t first[kMaxLevels + 1];      // first window of every level, and the total
+    hg_cascade_level lv[kMaxLevels];
+};
+
+__global__ void k_cascade_init_grid(LevelTable T, double* __restrict__ orig_coords, double* __restrict__ orig_level, double* __restrict__ coords,
+                                    double* __restrict__ angles, double* __restrict__ neg, double* __restrict__ conf, int32_t* __restrict__ oidx,
+                                    int32_t* __restrict__ count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = T.first[T.n_levels];
+    if (i == 0 && count) *count = n;
+    if (i >= n) return;
+    int L = 0;
+    while (L + 1 < T.n_levels && i >= T.first[L + 1]) ++L;
+    const hg_cascade_level& V = T.lv[L];
+    const int k = i - T.first[L], iy = k / V.nx, ix = k - iy * V.nx;
+    auto lin = [](int j, int num, double stop) -> double {
+        if (num <= 1 || j == 0) return 0.0;
+        if (j == num - 1) return stop;
+        return __dmul_rn((double)j, __ddiv_rn(stop, (double)(num - 1)));
+    };
+    const double x0 = lin(ix, V.nx, V.x_stop), y0 = lin(iy, V.ny, V.y_stop);
+    const double b[4] = {x0, y0, __dsub_rn(__dadd_rn(x0, V.patch_w), 1.0), __dsub_rn(__dadd_rn(y0, V.patch_h), 1.0)};
+    for (int q = 0; q < 4; ++q) orig_coords[(size_t)i * 4 + q] = b[q];
+    orig_level[(size_t)i * 3] = V.max_dx;
+    orig_level[(size_t)i * 3 + 1] = V.max_dy;
+    orig_level[(size_t)i * 3 + 2] = V.base_side;
+    if (coords) {
+        for (int q = 0; q < 4; ++q) coords[(size_t)i * 4 + q] = b[q];
+        angles[i] = 0.0;
+        neg[i] = 0.0;
+        conf[i] = 0.0;
+        oidx[i] = i;
+    }
+}
+
+// A GROUP of stages (round 5): a stage that owns a network and the stages behind it whose network is None read the SAME sl
+// (FaceDetectUpdated.py:678-682, :704-706; Pipelines/Pipeline_experimental.txt:8-19: PosX owns the flow, PosY / PAng / Scale
+// reuse it).  Rows are independent and a discard is per row, so the reference's m rounds of (regression, update, discard,
+// compaction) are ONE regression launch on the group's rows (hg_gauss_regression_multi_device: reg[s * stride + i]) and ONE glue
+// launch that applies the m updates and discard tests to every row in stage order — a row discarded at stage s takes no part in
+// the later ones, exactly as if it had been compacted away — and compacts once: the same survivors in the same order with the
+// same bits.  Survivor counts after every stage of the group are still produced (the reference counts them, :707).
+constexpr int kMaxGroup = hg::kGaussMaxMulti;
+struct GroupDesc {
+    int32_t m, pad;
+    int32_t type[kMaxGroup];
+    double cut[kMaxGroup];      // cut_offs_face[serial] of a Disc stage
+};
+
+// candidate i through the group's stages; returns whether it survives all of them, alive_after bit s = alive after stage s
+__device__ __forceinline__ bool group_one(const GroupDesc& G, const hg_cascade_consts& c0, const StageArrays& A, int64_t reg_stride, int i, double& x0,
+                                          double& y0, double& x1, double& y1, double& ang, double& cf, int32_t oi, unsigned& alive_after) {
+    bool alive = true;
+    alive_after = 0;
+    for (int s = 0; s < G.m; ++s) {
+        if (alive) {
+            const double r = A.reg[(size_t)s * reg_stride + i];
+            hg_cascade_consts c = c0;
+            c.cut_off_face = G.cut[s];
+            const bool wrong = update_one(G.type[s], c, x0, y0, x1, y1, ang, r, A.orig_coords + (size_t)oi * 4, A.orig_angles[oi], A.orig_level + (size_t)oi * 3);
+            if (G.type[s] == HG_STAGE_DISC) cf = r;      // FaceDetectUpdated.py:758-759
+            alive = !wrong;
+        }
+        alive_after |= (alive ? 1u : 0u) << s;
+    }
+    return alive;
+}
+
+// host_count (pinned): {count, sequence number, survivors after stage 0 .. m-1 of the group}
+__device__ __forceinline__ void publish_group(int32_t* host_count, const int* scount, int m, int cnt, int seq) {
+    for (int s = 0; s + 1 < m; ++s) host_count[2 + s] = scount[s];
+    host_count[2 + m - 1] = cnt;
+    publish_count(host_count, cnt, seq);
+}
+
+// One workgroup of 1024 threads (a frame has at most a few thousand candidates).
+__global__ void __launch_bounds__(1024) k_cascade_group(GroupDesc G, hg_cascade_consts c, StageArrays A, int64_t reg_stride, int32_t* host_count, int seq, HostResults H) {
     __shared__ int wsum[16];
     __shared__ int base;
+    __shared__ int scount[kMaxGroup];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = min(*A.count_in, A.n_max);
     const int cur = A.cur, nxt = 1 - cur;
     if (tid == 0) base = 0;
+    if (tid < kMaxGroup) scount[tid] = 0;
     __syncthreads();
     for (int i0 = 0; i0 < n; i0 += blockDim.x) {
         const int i = i0 + tid;
         int keep = 0;
-        double x0 = 0, y0 = 0, x1 = 0, y1 = 0, ang = 0, r = 0;
+        double x0 = 0, y0 = 0, x1 = 0, y1 = 0, ang = 0, cf = 0;
         int32_t oi = 0;
+        unsigned after = 0;
         if (i < n) {
             x0 = A.coords[cur][i * 4]; y0 = A.coords[cur][i * 4 + 1]; x1 = A.coords[cur][i * 4 + 2]; y1 = A.coords[cur][i * 4 + 3];
             ang = A.angles[cur][i];
-            r = A.reg[i];
+            cf = A.conf[cur][i];
             oi = A.oidx[cur][i];
-            keep = update_one(type, c, x0, y0, x1, y1, ang, r, A.orig_coords + (size_t)oi * 4, A.orig_angles[oi], A.orig_level + (size_t)oi * 3) ? 0 : 1;
+            keep = group_one(G, c, A, reg_stride, i, x0, y0, x1, y1, ang, cf, oi, after) ? 1 : 0;
+        }
+        for (int s = 0; s + 1 < G.m; ++s) {      // survivors after the group's inner stages (the last stage's count is the compaction's)
+            const unsigned long long ms = __ballot((after >> s) & 1u);
+            if (lane == 0 && ms) atomicAdd(&scount[s], (int)__popcll(ms));
         }
         const unsigned long long m = __ballot(keep);
         const int before = __popcll(m & ((1ull << lane) - 1ull));
@@ -255,7 +346,7 @@ __device__ __forceinline__ void cascade_stage_body(int type, const hg_cascade_co
             A.angles[nxt][j] = ang;
             A.neg_angles[j] = -ang;                                         // what the next extraction is called with (face_analysis.py:782)
             A.oidx[nxt][j] = oi;
-            A.conf[nxt][j] = type == HG_STAGE_DISC ? r : A.conf[cur][i];     // FaceDetectUpdated.py:758-759
+            A.conf[nxt][j] = cf;
         }
         __syncthreads();
         if (tid == 0) {
@@ -272,7 +363,7 @@ __device__ __forceinline__ void cascade_stage_body(int type, const hg_cascade_co
         const int j = e / kf, f = e - j * kf;
         A.sl[nxt][(size_t)j * kf + f] = A.sl[cur][(size_t)A.map[j] * kf + f];
     }
-    if (H.cap > 0 && cnt <= H.cap) {      // last stage: the survivors themselves, for the host (nxt[] is complete: barrier)
+    if (H.cap > 0 && cnt <= H.cap) {      // last group: the survivors themselves, for the host (nxt[] is complete: barrier)
         __syncthreads();
         for (int j = tid; j < cnt; j += blockDim.x) {
             for (int q = 0; q < 4; ++q) H.coords[(size_t)j * 4 + q] = A.coords[nxt][(size_t)j * 4 + q];
@@ -285,12 +376,8 @@ __device__ __forceinline__ void cascade_stage_body(int type, const hg_cascade_co
     }
     if (tid == 0) {
         *A.count_out = cnt;
-        if (host_count) publish_count(host_count, cnt, seq);
+        if (host_count) publish_group(host_count, scount, G.m, cnt, seq);
     }
-}
-
-__global__ void __launch_bounds__(1024) k_cascade_stage(int type, hg_cascade_consts c, StageArrays A, int32_t* host_count, int seq, HostResults H) {
-    cascade_stage_body(type, c, A, host_count, seq, H);
 }
 
 // (Round 4 measured regression AND glue of a stage as ONE launch — a workgroup per R candidates runs the regression of its rows,
@@ -298,47 +385,52 @@ __global__ void __launch_bounds__(1024) k_cascade_stage(int type, hg_cascade_con
 // against 8.7 + 5.4 for the two launches (1.57 against 1.49 ms per frame; with a device-scope fence instead of write-through
 // stores 1.66: the fence writes back the whole L2 of the workgroup's XCD).  Not kept.)
 
-// The same stage for batches of many frames' windows (the single workgroup above walks 1024 candidates per step): two launches
+// The same group for batches of many frames' windows (the single workgroup above walks 1024 candidates per step): two launches
 // of one workgroup per kChunk candidates.  `mark` updates every candidate IN PLACE in the cur arrays (nobody else reads them any
-// more), writes its keep flag and the chunk's survivor count; `scatter` turns the chunk counts into its base offset (a sum over
-// the chunks before it), repeats the chunk-local scan on the flags and moves the survivors, order preserved, into the nxt arrays.
+// more), writes its keep flag and the chunk's survivor counts (one per stage of the group); `scatter` turns the chunk counts into
+// its base offset (a sum over the chunks before it), repeats the chunk-local scan on the flags and moves the survivors, order
+// preserved, into the nxt arrays.
 constexpr int kChunk = 4096;
 
-__global__ void __launch_bounds__(1024) k_cascade_stage_mark(int type, hg_cascade_consts c, StageArrays A, int32_t* __restrict__ chunk_count) {
-    __shared__ int wsum[16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__global__ void __launch_bounds__(1024) k_cascade_group_mark(GroupDesc G, hg_cascade_consts c, StageArrays A, int64_t reg_stride, int32_t* __restrict__ chunk_count) {
+    __shared__ int scount[kMaxGroup];
+    const int tid = threadIdx.x, lane = tid & 63;
     const int n = min(*A.count_in, A.n_max), cur = A.cur;
     const int lo = blockIdx.x * kChunk, hi = min(n, lo + kChunk);
-    int kept = 0;
-    for (int i = lo + tid; i < hi; i += blockDim.x) {
-        double x0 = A.coords[cur][(size_t)i * 4], y0 = A.coords[cur][(size_t)i * 4 + 1], x1 = A.coords[cur][(size_t)i * 4 + 2], y1 = A.coords[cur][(size_t)i * 4 + 3];
-        double ang = A.angles[cur][i];
-        const int32_t oi = A.oidx[cur][i];
-        const bool wrong = update_one(type, c, x0, y0, x1, y1, ang, A.reg[i], A.orig_coords + (size_t)oi * 4, A.orig_angles[oi], A.orig_level + (size_t)oi * 3);
-        A.coords[cur][(size_t)i * 4] = x0; A.coords[cur][(size_t)i * 4 + 1] = y0; A.coords[cur][(size_t)i * 4 + 2] = x1; A.coords[cur][(size_t)i * 4 + 3] = y1;
-        A.angles[cur][i] = ang;
-        A.discard[i] = wrong ? 1 : 0;
-        kept += wrong ? 0 : 1;
-    }
-    for (int o = 32; o > 0; o >>= 1) kept += __shfl_xor(kept, o);
-    if (lane == 0) wsum[wave] = kept;
+    if (tid < kMaxGroup) scount[tid] = 0;
     __syncthreads();
-    if (tid == 0) {
-        int t = 0;
-        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += wsum[w];
-        chunk_count[blockIdx.x] = t;
+    for (int i0 = lo; i0 < hi; i0 += blockDim.x) {
+        const int i = i0 + tid;
+        unsigned after = 0;
+        if (i < hi) {
+            double x0 = A.coords[cur][(size_t)i * 4], y0 = A.coords[cur][(size_t)i * 4 + 1], x1 = A.coords[cur][(size_t)i * 4 + 2], y1 = A.coords[cur][(size_t)i * 4 + 3];
+            double ang = A.angles[cur][i], cf = A.conf[cur][i];
+            const int32_t oi = A.oidx[cur][i];
+            const bool keep = group_one(G, c, A, reg_stride, i, x0, y0, x1, y1, ang, cf, oi, after);
+            A.coords[cur][(size_t)i * 4] = x0; A.coords[cur][(size_t)i * 4 + 1] = y0; A.coords[cur][(size_t)i * 4 + 2] = x1; A.coords[cur][(size_t)i * 4 + 3] = y1;
+            A.angles[cur][i] = ang;
+            A.conf[cur][i] = cf;
+            A.discard[i] = keep ? 0 : 1;
+        }
+        for (int s = 0; s < G.m; ++s) {
+            const unsigned long long ms = __ballot((after >> s) & 1u);
+            if (lane == 0 && ms) atomicAdd(&scount[s], (int)__popcll(ms));
+        }
     }
+    __syncthreads();
+    if (tid < kMaxGroup) chunk_count[blockIdx.x * kMaxGroup + tid] = scount[tid];
 }
 
-__global__ void __launch_bounds__(1024) k_cascade_stage_scatter(int type, StageArrays A, const int32_t* __restrict__ chunk_count, int32_t* host_count, int seq) {
+__global__ void __launch_bounds__(1024) k_cascade_group_scatter(int m, StageArrays A, const int32_t* __restrict__ chunk_count, int32_t* host_count, int seq) {
     __shared__ int wsum[16];
     __shared__ int base;
+    __shared__ int stot[kMaxGroup];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = min(*A.count_in, A.n_max), cur = A.cur, nxt = 1 - cur;
     const int lo = blockIdx.x * kChunk, hi = min(n, lo + kChunk);
-    // base = survivors of the chunks before this one (the last workgroup also learns the total)
+    // base = survivors of the chunks before this one (the last workgroup also learns the totals)
     int part = 0;
-    for (int b = tid; b < (int)blockIdx.x; b += blockDim.x) part += chunk_count[b];
+    for (int b = tid; b < (int)blockIdx.x; b += blockDim.x) part += chunk_count[b * kMaxGroup + m - 1];
     for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
     if (lane == 0) wsum[wave] = part;
     __syncthreads();
@@ -352,9 +444,9 @@ __global__ void __launch_bounds__(1024) k_cascade_stage_scatter(int type, StageA
     for (int i0 = lo; i0 < hi; i0 += blockDim.x) {
         const int i = i0 + tid;
         const int keep = (i < hi && A.discard[i] == 0) ? 1 : 0;
-        const unsigned long long m = __ballot(keep);
-        const int before = __popcll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) wsum[wave] = __popcll(m);
+        const unsigned long long mk = __ballot(keep);
+        const int before = __popcll(mk & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(mk);
         __syncthreads();
         int off = base;
         for (int w = 0; w < wave; ++w) off += wsum[w];
@@ -366,7 +458,7 @@ __global__ void __launch_bounds__(1024) k_cascade_stage_scatter(int type, StageA
             A.angles[nxt][j] = ang;
             A.neg_angles[j] = -ang;
             A.oidx[nxt][j] = A.oidx[cur][i];
-            A.conf[nxt][j] = type == HG_STAGE_DISC ? A.reg[i] : A.conf[cur][i];
+            A.conf[nxt][j] = A.conf[cur][i];
             for (int f = 0; f < kf; ++f) A.sl[nxt][(size_t)j * kf + f] = A.sl[cur][(size_t)i * kf + f];
         }
         __syncthreads();
@@ -377,9 +469,22 @@ __global__ void __launch_bounds__(1024) k_cascade_stage_scatter(int type, StageA
         }
         __syncthreads();
     }
-    if (blockIdx.x == gridDim.x - 1 && tid == 0) {      // the last chunk's end offset is the total
-        *A.count_out = base;
-        if (host_count) publish_count(host_count, base, seq);
+    if (blockIdx.x == gridDim.x - 1) {      // the last chunk's end offset is the total
+        if (host_count) {      // totals of the inner stages, for the host
+            if (tid < kMaxGroup) stot[tid] = 0;
+            __syncthreads();
+            for (int s = 0; s + 1 < m; ++s) {
+                int t = 0;
+                for (int b = tid; b < (int)gridDim.x; b += blockDim.x) t += chunk_count[b * kMaxGroup + s];
+                for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+                if (lane == 0 && t) atomicAdd(&stot[s], t);
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            *A.count_out = base;
+            if (host_count) publish_group(host_count, stot, m, base, seq);
+        }
     }
 }
 
@@ -448,6 +553,8 @@ struct hg_cascade {
     hg_patcher* patcher = nullptr;
     int64_t cap = 0;
     hg::DevBuf coords[2], angles[2], conf[2], oidx[2], sl[2], subs[2], neg, reg, discard, map, count, orig_coords, orig_level, orig_angles, chunk_count;
+    hg::DevBuf pre_box, pre_frame;       // hg_cascade_detect_frame_device: the box of the whole frame and the prescaled frame
+    int pre_src_w = 0, pre_src_h = 0;    // ... the frame size pre_box was written for
     int32_t* host_count = nullptr;       // pinned, device-visible: {count, sequence number} (publish_count)
     int32_t seq = 0;                     // sequence number of the last read-back asked for
     char* host_res = nullptr;            // pinned: the final survivors (HostResults), kResCap rows
@@ -464,7 +571,7 @@ struct hg_cascade {
             subs[b].alloc((size_t)n0 * w * h);
         }
         neg.alloc((size_t)n0 * 8);
-        reg.alloc((size_t)n0 * 8);
+        reg.alloc((size_t)n0 * 8 * kMaxGroup);      // regressions of a group of stages: [stage of the group][candidate], stride = cap
         discard.alloc((size_t)n0);
         map.alloc((size_t)n0 * 4);
         count.alloc(16);
@@ -518,154 +625,274 @@ void hg_cascade_free(hg_cascade* c) {
     delete c;
 }
 
+}  // extern "C"
+
+namespace {
+
+LevelTable make_level_table(const hg_cascade_level* levels, int n_levels) {
+    if (!levels || n_levels < 1 || n_levels > kMaxLevels) hg::fail(HG_ERR_ARG, "1..%d pyramid levels", kMaxLevels);
+    LevelTable T{};
+    T.n_levels = n_levels;
+    int64_t tot = 0;
+    for (int L = 0; L < n_levels; ++L) {
+        const hg_cascade_level& v = levels[L];
+        if (v.nx < 1 || v.ny < 1 || (int64_t)v.nx * v.ny > 0x7fffffffll / 64) hg::fail(HG_ERR_ARG, "level %d: bad grid %d x %d", L, v.nx, v.ny);
+        T.first[L] = (int32_t)tot;
+        tot += (int64_t)v.nx * v.ny;
+        if (tot > 0x7fffffffll / 64) hg::fail(HG_ERR_ARG, "too many windows");
+        T.lv[L] = v;
+    }
+    T.first[n_levels] = (int32_t)tot;
+    return T;
+}
+
+// The stage loop.  `T`: the windows come from the grid's closed form (k_cascade_init_grid), else from boxes_host / level_host.
+void detect_impl(hg_cascade* c, const void* frame_dev, int frame_h, int frame_w, int64_t ld, const double* boxes_host, const double* level_host,
+                 const LevelTable* T, int64_t n0, double* out_coords, double* out_angles, int32_t* out_orig_index, double* out_confidence,
+                 int64_t out_cap, int64_t* n_out, int32_t* stage_counts, int64_t* rows_executed, void* stream) {
+    if (!c || !n_out) hg::fail(HG_ERR_ARG, "null argument");
+    if (n0 < 0 || n0 > 0x7fffffffll / 64) hg::fail(HG_ERR_ARG, "bad window count");
+    if (n0 > 0 && (!frame_dev || (!T && (!boxes_host || !level_host)))) hg::fail(HG_ERR_ARG, "null data pointer");
+    set_dev(c->device);
+    hipStream_t st = (hipStream_t)stream;
+    const int ns = (int)c->stages.size();
+    *n_out = 0;
+    if (rows_executed) *rows_executed = 0;
+    if (n0 == 0) {
+        for (int k = 0; k < ns && stage_counts; ++k) stage_counts[k] = 0;
+        return;
+    }
+    c->reserve(n0);
+    if (T) {
+        hipLaunchKernelGGL(k_cascade_init_grid, (unsigned)((n0 + 255) / 256), 256, 0, st, *T, (double*)c->orig_coords.p, (double*)c->orig_level.p,
+                           (double*)c->coords[0].p, (double*)c->angles[0].p, (double*)c->neg.p, (double*)c->conf[0].p, (int32_t*)c->oidx[0].p,
+                           (int32_t*)c->count.p);
+    } else {
+        HG_HIP(hipMemcpyAsync(c->orig_coords.p, boxes_host, (size_t)n0 * 32, hipMemcpyHostToDevice, st));
+        HG_HIP(hipMemcpyAsync(c->orig_level.p, level_host, (size_t)n0 * 24, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_cascade_init, (unsigned)((n0 + 255) / 256), 256, 0, st, (int)n0, (const double*)c->orig_coords.p, (double*)c->coords[0].p,
+                           (double*)c->angles[0].p, (double*)c->neg.p, (double*)c->conf[0].p, (int32_t*)c->oidx[0].p, (int32_t*)c->count.p);
+    }
+    HG_HIP(hipGetLastError());
+    // the count word is polled, never waited for with a stream synchronisation (publish_count); a deadline guards against a
+    // device that never answers
+    auto poll_count = [&](int32_t seq) -> int64_t {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0;; ++spins) {
+            if (__atomic_load_n(c->host_count + 1, __ATOMIC_ACQUIRE) == seq) return c->host_count[0];
+            if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
+                HG_HIP(hipStreamSynchronize(st));
+                if (__atomic_load_n(c->host_count + 1, __ATOMIC_ACQUIRE) == seq) return c->host_count[0];
+                hg::fail(HG_ERR_DEVICE, "cascade stage did not report its survivor count");
+            }
+            __builtin_ia32_pause();
+        }
+    };
+    HostResults H{};
+    H.coords = (double*)c->host_res;
+    H.angles = (double*)(c->host_res + (size_t)hg_cascade::kResCap * 32);
+    H.conf = (double*)(c->host_res + (size_t)hg_cascade::kResCap * 40);
+    H.oidx = (int32_t*)(c->host_res + (size_t)hg_cascade::kResCap * 48);
+    bool results_on_host = false;
+    int cur = 0, cnt_slot = 0;
+    int sb = 0;                                    // which of subs[] holds the extracted sub-images, row-aligned with the candidates
+    int64_t n_bound = n0, rows = 0;                // n_bound: host-side upper bound of the candidate count (exact after a Disc stage)
+    const size_t row = (size_t)c->w * c->h;
+    // The reference compacts subimages_arr after EVERY stage (FaceDetectUpdated.py:753) and reuses it in a stage that follows a
+    // Disc stage and owns a network (:674-681).  Here the rows travel only while a later stage will read them before the next
+    // extraction replaces them: carry[k] = "stage k's survivors' sub-images are needed again".  (In the shipped pipeline that is
+    // after Disc1 / Disc3 / Disc5 / Disc7 only; a pipeline such as PosX(net), Disc(None), PosX(net) carries them through two stages.)
+    std::vector<char> carry((size_t)ns, 0);
+    {
+        bool need = false;                         // need at the entry of stage k + 1
+        for (int k = ns - 1; k >= 0; --k) {
+            carry[(size_t)k] = need;
+            const bool prev_disc = k > 0 && c->stages[k - 1].type == HG_STAGE_DISC;
+            if (c->stages[k].flow) need = prev_disc;          // reuses them (needs them at entry) or extracts afresh (does not)
+        }
+    }
+    const bool no_groups = getenv("HIGSFA_CASCADE_NO_GROUPS") != nullptr;      // every stage a group of its own (tests, A/B); read per frame
+    for (int k = 0; k < ns;) {
+        // the group: stage k and the stages behind it that have no network of their own (they read the same sl), at most kMaxGroup
+        int m = 1;
+        while (!no_groups && k + m < ns && m < kMaxGroup && !c->stages[k + m].flow) ++m;
+        const hg_cascade_stage& S = c->stages[k];
+        if (n_bound == 0) {
+            for (int s = 0; s < m && stage_counts; ++s) stage_counts[k + s] = 0;
+            k += m;
+            continue;
+        }
+        const bool skip_extract = (k > 0 && c->stages[k - 1].type == HG_STAGE_DISC) || !S.flow;      // FaceDetectUpdated.py:674-681
+        if (!skip_extract) {
+            // (the first stage's angles are all zero: the plain EXTENT kernel — a window with delta_ang == 0 is cut from the frame itself)
+            if (hg_patcher_extract_rotate_device(c->patcher, frame_dev, HG_U8, frame_h, frame_w, ld, (const double*)c->coords[cur].p,
+                                                 k == 0 ? nullptr : (const double*)c->neg.p, n_bound, c->w, c->h, c->subs[sb].p, HG_U8, (int64_t)row, st) != HG_OK)
+                hg::fail(HG_ERR_DEVICE, "%s", hg_last_error());
+        }
+        if (S.flow) {
+            if (hg_flow_execute_device(S.flow, c->subs[sb].p, HG_U8, n_bound, (int64_t)row, c->sl[cur].p, HG_F32, c->k, c->k, st) != HG_OK)
+                hg::fail(HG_ERR_DEVICE, "%s", hg_last_error());
+            rows += n_bound;
+        }
+        GroupDesc G{};
+        G.m = m;
+        hg_gauss* clf[kMaxGroup] = {};
+        bool any_disc = false;
+        for (int s = 0; s < m; ++s) {
+            const hg_cascade_stage& Ss = c->stages[k + s];
+            G.type[s] = Ss.type;
+            G.cut[s] = c->cut_offs[Ss.serial];
+            clf[s] = Ss.classifier;
+            any_disc = any_disc || Ss.type == HG_STAGE_DISC;
+        }
+        // the group's regressions, all on the rows of sl[cur]: reg[s * cap + i]
+        if (hg_gauss_regression_multi_device(clf, m, c->sl[cur].p, HG_F32, n_bound, c->k, (double*)c->reg.p, c->cap, st) != HG_OK)
+            hg::fail(HG_ERR_DEVICE, "%s", hg_last_error());
+        StageArrays A{};
+        for (int b = 0; b < 2; ++b) {
+            A.coords[b] = (double*)c->coords[b].p;
+            A.angles[b] = (double*)c->angles[b].p;
+            A.conf[b] = (double*)c->conf[b].p;
+            A.oidx[b] = (int32_t*)c->oidx[b].p;
+            A.sl[b] = (float*)c->sl[b].p;
+        }
+        A.neg_angles = (double*)c->neg.p;
+        A.reg = (const double*)c->reg.p;
+        A.orig_coords = (const double*)c->orig_coords.p;
+        A.orig_angles = (const double*)c->orig_angles.p;
+        A.orig_level = (const double*)c->orig_level.p;
+        A.discard = (uint8_t*)c->discard.p;
+        A.map = (int32_t*)c->map.p;
+        A.count_in = (int32_t*)c->count.p + cnt_slot;
+        A.count_out = (int32_t*)c->count.p + (1 - cnt_slot);
+        A.k_feat = c->k;
+        A.cur = cur;
+        A.n_max = (int32_t)n_bound;
+        // the host needs the exact count where it shrinks and sizes the next launches: after every group with a Disc stage (the
+        // read-back is a poll of a pinned word, cheap enough for the small stages too), and at the end
+        const bool last = k + m == ns;
+        const bool want_count = any_disc || last;
+        const int32_t seq = want_count ? ++c->seq : 0;
+        HostResults Hk{};
+        if (n_bound > 2 * kChunk) {      // many frames' windows: one workgroup per kChunk candidates, two launches
+            const unsigned chunks = (unsigned)((n_bound + kChunk - 1) / kChunk);
+            c->chunk_count.alloc((size_t)chunks * kMaxGroup * 4);
+            hipLaunchKernelGGL(k_cascade_group_mark, chunks, 1024, 0, st, G, c->base, A, c->cap, (int32_t*)c->chunk_count.p);
+            hipLaunchKernelGGL(k_cascade_group_scatter, chunks, 1024, 0, st, m, A, (const int32_t*)c->chunk_count.p, want_count ? c->host_count : nullptr, seq);
+        } else {
+            if (last && n_bound <= hg_cascade::kResCap) {
+                Hk = H;
+                Hk.cap = hg_cascade::kResCap;
+                results_on_host = true;
+            }
+            hipLaunchKernelGGL(k_cascade_group, 1, 1024, 0, st, G, c->base, A, c->cap, want_count ? c->host_count : nullptr, seq, Hk);
+        }
+        if (carry[(size_t)(k + m - 1)]) {       // the group's compaction applied to the sub-images as well (:753)
+            const int vec16 = row % 16 == 0 ? 1 : 0;
+            hipLaunchKernelGGL(k_gather_rows, (unsigned)std::min<int64_t>(n_bound, 16384), 256, 0, st, (const char*)c->subs[sb].p, (char*)c->subs[1 - sb].p,
+                               (int64_t)row, (const int32_t*)c->map.p, (const int32_t*)A.count_out, vec16);
+            sb = 1 - sb;
+        }
+        HG_HIP(hipGetLastError());
+        cur = 1 - cur;
+        cnt_slot = 1 - cnt_slot;
+        if (want_count) {
+            n_bound = poll_count(seq);
+            for (int s = 0; s < m && stage_counts; ++s) stage_counts[k + s] = c->host_count[2 + s];      // written before the sequence number
+        } else {
+            for (int s = 0; s < m && stage_counts; ++s) stage_counts[k + s] = -1;      // not read back (no stage of the group discards by a cut-off: bound of the last Disc stage)
+        }
+        k += m;
+    }
+    if (n_bound > out_cap) hg::fail(HG_ERR_ARG, "%lld detections but room for %lld", (long long)n_bound, (long long)out_cap);
+    if (n_bound > 0 && results_on_host) {      // written by the last group's kernel before it published the count
+        if (out_coords) memcpy(out_coords, H.coords, (size_t)n_bound * 32);
+        if (out_angles) memcpy(out_angles, H.angles, (size_t)n_bound * 8);
+        if (out_orig_index) memcpy(out_orig_index, H.oidx, (size_t)n_bound * 4);
+        if (out_confidence) memcpy(out_confidence, H.conf, (size_t)n_bound * 8);
+    } else if (n_bound > 0) {
+        if (out_coords) HG_HIP(hipMemcpyAsync(out_coords, c->coords[cur].p, (size_t)n_bound * 32, hipMemcpyDeviceToHost, st));
+        if (out_angles) HG_HIP(hipMemcpyAsync(out_angles, c->angles[cur].p, (size_t)n_bound * 8, hipMemcpyDeviceToHost, st));
+        if (out_orig_index) HG_HIP(hipMemcpyAsync(out_orig_index, c->oidx[cur].p, (size_t)n_bound * 4, hipMemcpyDeviceToHost, st));
+        if (out_confidence) HG_HIP(hipMemcpyAsync(out_confidence, c->conf[cur].p, (size_t)n_bound * 8, hipMemcpyDeviceToHost, st));
+        HG_HIP(hipStreamSynchronize(st));
+    }
+    *n_out = n_bound;
+    if (rows_executed) *rows_executed = rows;
+}
+
+}  // namespace
+
+extern "C" {
+
 int hg_cascade_detect_device(hg_cascade* c, const void* frame_dev, int frame_h, int frame_w, int64_t ld, const double* boxes_host,
                              const double* level_host, int64_t n0, double* out_coords, double* out_angles, int32_t* out_orig_index,
                              double* out_confidence, int64_t out_cap, int64_t* n_out, int32_t* stage_counts, int64_t* rows_executed,
                              void* stream) {
     return guarded([&] {
-        if (!c || !n_out) hg::fail(HG_ERR_ARG, "null argument");
-        if (n0 < 0 || n0 > 0x7fffffffll / 64) hg::fail(HG_ERR_ARG, "bad window count");
-        if (n0 > 0 && (!frame_dev || !boxes_host || !level_host)) hg::fail(HG_ERR_ARG, "null data pointer");
-        set_dev(c->device);
-        hipStream_t st = (hipStream_t)stream;
-        const int ns = (int)c->stages.size();
-        *n_out = 0;
-        if (rows_executed) *rows_executed = 0;
-        if (n0 == 0) {
-            for (int k = 0; k < ns && stage_counts; ++k) stage_counts[k] = 0;
-            return;
-        }
-        c->reserve(n0);
-        HG_HIP(hipMemcpyAsync(c->orig_coords.p, boxes_host, (size_t)n0 * 32, hipMemcpyHostToDevice, st));
-        HG_HIP(hipMemcpyAsync(c->orig_level.p, level_host, (size_t)n0 * 24, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_cascade_init, (unsigned)((n0 + 255) / 256), 256, 0, st, (int)n0, (const double*)c->orig_coords.p, (double*)c->coords[0].p,
-                           (double*)c->angles[0].p, (double*)c->neg.p, (double*)c->conf[0].p, (int32_t*)c->oidx[0].p, (int32_t*)c->count.p);
-        HG_HIP(hipGetLastError());
-        // the count word is polled, never waited for with a stream synchronisation (publish_count); a deadline guards against a
-        // device that never answers
-        auto poll_count = [&](int32_t seq) -> int64_t {
-            const auto t0 = std::chrono::steady_clock::now();
-            for (unsigned spins = 0;; ++spins) {
-                if (__atomic_load_n(c->host_count + 1, __ATOMIC_ACQUIRE) == seq) return c->host_count[0];
-                if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
-                    HG_HIP(hipStreamSynchronize(st));
-                    if (__atomic_load_n(c->host_count + 1, __ATOMIC_ACQUIRE) == seq) return c->host_count[0];
-                    hg::fail(HG_ERR_DEVICE, "cascade stage did not report its survivor count");
-                }
-                __builtin_ia32_pause();
+        detect_impl(c, frame_dev, frame_h, frame_w, ld, boxes_host, level_host, nullptr, n0, out_coords, out_angles, out_orig_index, out_confidence,
+                    out_cap, n_out, stage_counts, rows_executed, stream);
+    });
+}
+
+int hg_cascade_detect_levels_device(hg_cascade* c, const void* frame_dev, int frame_h, int frame_w, int64_t ld, const hg_cascade_level* levels,
+                                    int n_levels, double* out_coords, double* out_angles, int32_t* out_orig_index, double* out_confidence,
+                                    int64_t out_cap, int64_t* n_out, int32_t* stage_counts, int64_t* rows_executed, void* stream) {
+    return guarded([&] {
+        const LevelTable T = make_level_table(levels, n_levels);
+        detect_impl(c, frame_dev, frame_h, frame_w, ld, nullptr, nullptr, &T, T.first[T.n_levels], out_coords, out_angles, out_orig_index,
+                    out_confidence, out_cap, n_out, stage_counts, rows_executed, stream);
+    });
+}
+
+int hg_cascade_detect_frame_device(hg_cascade* c, const void* frame_dev, int frame_h, int frame_w, int64_t ld, int prescale_w, int prescale_h,
+                                   const hg_cascade_level* levels, int n_levels, double* out_coords, double* out_angles, int32_t* out_orig_index,
+                                   double* out_confidence, int64_t out_cap, int64_t* n_out, int32_t* stage_counts, int64_t* rows_executed, void* stream) {
+    return guarded([&] {
+        if (!c) hg::fail(HG_ERR_ARG, "null argument");
+        const LevelTable T = make_level_table(levels, n_levels);
+        const void* fr = frame_dev;
+        int fh = frame_h, fw = frame_w;
+        int64_t fld = ld;
+        if (prescale_w > 0 || prescale_h > 0) {
+            // FaceDetectUpdated.py:551-561: im.resize((w, h), NEAREST) before the grid is laid out — PIL's nearest resize is the EXTENT
+            // rule over the whole frame (tested against PIL), so the patcher does it, into a buffer that lives with the cascade
+            if (prescale_w <= 0 || prescale_h <= 0 || !frame_dev) hg::fail(HG_ERR_ARG, "bad prescale size %d x %d", prescale_w, prescale_h);
+            set_dev(c->device);
+            if (c->pre_src_w != frame_w || c->pre_src_h != frame_h) {
+                const double box[4] = {0.0, 0.0, (double)frame_w, (double)frame_h};
+                c->pre_box.upload(box, sizeof box);
+                c->pre_src_w = frame_w;
+                c->pre_src_h = frame_h;
             }
-        };
-        HostResults H{};
-        H.coords = (double*)c->host_res;
-        H.angles = (double*)(c->host_res + (size_t)hg_cascade::kResCap * 32);
-        H.conf = (double*)(c->host_res + (size_t)hg_cascade::kResCap * 40);
-        H.oidx = (int32_t*)(c->host_res + (size_t)hg_cascade::kResCap * 48);
-        bool results_on_host = false;
-        int cur = 0, cnt_slot = 0;
-        int sb = 0;                                    // which of subs[] holds the extracted sub-images, row-aligned with the candidates
-        int64_t n_bound = n0, rows = 0;                // n_bound: host-side upper bound of the candidate count (exact after a Disc stage)
-        const size_t row = (size_t)c->w * c->h;
-        // The reference compacts subimages_arr after EVERY stage (FaceDetectUpdated.py:753) and reuses it in a stage that follows a
-        // Disc stage and owns a network (:674-681).  Here the rows travel only while a later stage will read them before the next
-        // extraction replaces them: carry[k] = "stage k's survivors' sub-images are needed again".  (In the shipped pipeline that is
-        // after Disc1 / Disc3 / Disc5 / Disc7 only; a pipeline such as PosX(net), Disc(None), PosX(net) carries them through two stages.)
-        std::vector<char> carry((size_t)ns, 0);
-        {
-            bool need = false;                         // need at the entry of stage k + 1
-            for (int k = ns - 1; k >= 0; --k) {
-                carry[(size_t)k] = need;
-                const bool prev_disc = k > 0 && c->stages[k - 1].type == HG_STAGE_DISC;
-                if (c->stages[k].flow) need = prev_disc;          // reuses them (needs them at entry) or extracts afresh (does not)
-            }
-        }
-        for (int k = 0; k < ns; ++k) {
-            const hg_cascade_stage& S = c->stages[k];
-            if (n_bound == 0) {
-                if (stage_counts) stage_counts[k] = 0;
-                continue;
-            }
-            const bool skip_extract = (k > 0 && c->stages[k - 1].type == HG_STAGE_DISC) || !S.flow;      // FaceDetectUpdated.py:674-681
-            if (!skip_extract) {
-                if (hg_patcher_extract_rotate_device(c->patcher, frame_dev, HG_U8, frame_h, frame_w, ld, (const double*)c->coords[cur].p,
-                                                     (const double*)c->neg.p, n_bound, c->w, c->h, c->subs[sb].p, HG_U8, (int64_t)row, st) != HG_OK)
-                    hg::fail(HG_ERR_DEVICE, "%s", hg_last_error());
-            }
-            if (S.flow) {
-                if (hg_flow_execute_device(S.flow, c->subs[sb].p, HG_U8, n_bound, (int64_t)row, c->sl[cur].p, HG_F32, c->k, c->k, st) != HG_OK)
-                    hg::fail(HG_ERR_DEVICE, "%s", hg_last_error());
-                rows += n_bound;
-            }
-            if (hg_gauss_regression_device(S.classifier, c->sl[cur].p, HG_F32, n_bound, c->k, (double*)c->reg.p, nullptr, st) != HG_OK)
+            c->pre_frame.alloc((size_t)prescale_w * prescale_h);
+            if (hg_patcher_extract_device(c->patcher, frame_dev, HG_U8, frame_h, frame_w, ld, (const double*)c->pre_box.p, 1, prescale_w, prescale_h,
+                                          c->pre_frame.p, HG_U8, (int64_t)prescale_w * prescale_h, stream) != HG_OK)
                 hg::fail(HG_ERR_DEVICE, "%s", hg_last_error());
-            hg_cascade_consts cc = c->base;
-            cc.cut_off_face = c->cut_offs[S.serial];
-            StageArrays A{};
-            for (int b = 0; b < 2; ++b) {
-                A.coords[b] = (double*)c->coords[b].p;
-                A.angles[b] = (double*)c->angles[b].p;
-                A.conf[b] = (double*)c->conf[b].p;
-                A.oidx[b] = (int32_t*)c->oidx[b].p;
-                A.sl[b] = (float*)c->sl[b].p;
-            }
-            A.neg_angles = (double*)c->neg.p;
-            A.reg = (const double*)c->reg.p;
-            A.orig_coords = (const double*)c->orig_coords.p;
-            A.orig_angles = (const double*)c->orig_angles.p;
-            A.orig_level = (const double*)c->orig_level.p;
-            A.discard = (uint8_t*)c->discard.p;
-            A.map = (int32_t*)c->map.p;
-            A.count_in = (int32_t*)c->count.p + cnt_slot;
-            A.count_out = (int32_t*)c->count.p + (1 - cnt_slot);
-            A.k_feat = c->k;
-            A.cur = cur;
-            A.n_max = (int32_t)n_bound;
-            // the host needs the exact count where it shrinks and sizes the next launches: after every Disc stage (the read-back is a
-            // poll of a pinned word now, cheap enough for the small stages too), and at the end
-            const bool last = k + 1 == ns;
-            const bool want_count = S.type == HG_STAGE_DISC || last;
-            const int32_t seq = want_count ? ++c->seq : 0;
-            HostResults Hk{};
-            if (n_bound > 2 * kChunk) {      // many frames' windows: one workgroup per kChunk candidates, two launches
-                const unsigned chunks = (unsigned)((n_bound + kChunk - 1) / kChunk);
-                c->chunk_count.alloc((size_t)chunks * 4);
-                hipLaunchKernelGGL(k_cascade_stage_mark, chunks, 1024, 0, st, S.type, cc, A, (int32_t*)c->chunk_count.p);
-                hipLaunchKernelGGL(k_cascade_stage_scatter, chunks, 1024, 0, st, S.type, A, (const int32_t*)c->chunk_count.p, want_count ? c->host_count : nullptr, seq);
-            } else {
-                if (last && n_bound <= hg_cascade::kResCap) {
-                    Hk = H;
-                    Hk.cap = hg_cascade::kResCap;
-                    results_on_host = true;
-                }
-                hipLaunchKernelGGL(k_cascade_stage, 1, 1024, 0, st, S.type, cc, A, want_count ? c->host_count : nullptr, seq, Hk);
-            }
-            if (carry[(size_t)k]) {       // this stage's compaction applied to the sub-images as well (:753)
-                const int vec16 = row % 16 == 0 ? 1 : 0;
-                hipLaunchKernelGGL(k_gather_rows, (unsigned)std::min<int64_t>(n_bound, 16384), 256, 0, st, (const char*)c->subs[sb].p, (char*)c->subs[1 - sb].p,
-                                   (int64_t)row, (const int32_t*)c->map.p, (const int32_t*)A.count_out, vec16);
-                sb = 1 - sb;
-            }
-            HG_HIP(hipGetLastError());
-            cur = 1 - cur;
-            cnt_slot = 1 - cnt_slot;
-            if (want_count) n_bound = poll_count(seq);
-            if (stage_counts) stage_counts[k] = want_count ? (int32_t)n_bound : -1;      // -1: not read back (the stage cannot discard by a cut-off: bound of the last Disc stage)
+            fr = c->pre_frame.p;
+            fh = prescale_h;
+            fw = prescale_w;
+            fld = prescale_w;
         }
-        if (n_bound > out_cap) hg::fail(HG_ERR_ARG, "%lld detections but room for %lld", (long long)n_bound, (long long)out_cap);
-        if (n_bound > 0 && results_on_host) {      // written by the last stage's kernel before it published the count
-            if (out_coords) memcpy(out_coords, H.coords, (size_t)n_bound * 32);
-            if (out_angles) memcpy(out_angles, H.angles, (size_t)n_bound * 8);
-            if (out_orig_index) memcpy(out_orig_index, H.oidx, (size_t)n_bound * 4);
-            if (out_confidence) memcpy(out_confidence, H.conf, (size_t)n_bound * 8);
-        } else if (n_bound > 0) {
-            if (out_coords) HG_HIP(hipMemcpyAsync(out_coords, c->coords[cur].p, (size_t)n_bound * 32, hipMemcpyDeviceToHost, st));
-            if (out_angles) HG_HIP(hipMemcpyAsync(out_angles, c->angles[cur].p, (size_t)n_bound * 8, hipMemcpyDeviceToHost, st));
-            if (out_orig_index) HG_HIP(hipMemcpyAsync(out_orig_index, c->oidx[cur].p, (size_t)n_bound * 4, hipMemcpyDeviceToHost, st));
-            if (out_confidence) HG_HIP(hipMemcpyAsync(out_confidence, c->conf[cur].p, (size_t)n_bound * 8, hipMemcpyDeviceToHost, st));
-            HG_HIP(hipStreamSynchronize(st));
-        }
-        *n_out = n_bound;
-        if (rows_executed) *rows_executed = rows;
+        detect_impl(c, fr, fh, fw, fld, nullptr, nullptr, &T, T.first[T.n_levels], out_coords, out_angles, out_orig_index, out_confidence, out_cap,
+                    n_out, stage_counts, rows_executed, stream);
+    });
+}
+
+int hg_cascade_grid_device(int device, const hg_cascade_level* levels, int n_levels, double* boxes_dev, double* level_dev, int64_t cap, int64_t* n0,
+                           void* stream) {
+    return guarded([&] {
+        const LevelTable T = make_level_table(levels, n_levels);
+        const int64_t n = T.first[T.n_levels];
+        if (n0) *n0 = n;
+        if (!boxes_dev && !level_dev) return;      // a query of the window count
+        if (!boxes_dev || !level_dev || cap < n) hg::fail(HG_ERR_ARG, "room for %lld windows, the grid has %lld", (long long)cap, (long long)n);
+        set_dev(device);
+        hipLaunchKernelGGL(k_cascade_init_grid, (unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream, T, boxes_dev, level_dev, (double*)nullptr,
+                           (double*)nullptr, (double*)nullptr, (double*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr);
+        HG_HIP(hipGetLastError());
     });
 }
 
 }  // extern "C"
+

@@ -9,6 +9,7 @@
 // Evaluated in the log domain in fp64 (sqrtdet reaches 1e42 in the shipped classifiers).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 
 #include "hg_common.hpp"
@@ -101,6 +102,27 @@ __global__ void __launch_bounds__(256)
 k_gauss_regression_wg(const T* __restrict__ x, int64_t ldx, int64_t n, hg::GaussParams G, double* __restrict__ out_reg, double* __restrict__ out_std) {
     extern __shared__ double lds_g[];
     hg::gauss_rows_wg<T, R>(x, ldx, n, (int64_t)blockIdx.x * R, G, lds_g, out_reg, out_std);
+}
+
+// Several classifiers on the SAME feature rows in one launch (round 5: a cascade stage that owns a network and the "None" stages
+// behind it, FaceDetectUpdated.py:678-682 / :704-706, read one sl): blockIdx.y picks the classifier, regressions of classifier s
+// land in out_reg[s * out_stride + row].  The per-row arithmetic is gauss_rows_wg's, whatever the launch shape: the same bits
+// as one launch per classifier (tests/test_cascade.py compares them).
+struct GaussMulti {
+    hg::GaussParams g[hg::kGaussMaxMulti];
+};
+template <typename T, int R>
+__global__ void __launch_bounds__(256)
+k_gauss_regression_wg_multi(const T* __restrict__ x, int64_t ldx, int64_t n, GaussMulti M, double* __restrict__ out_reg, int64_t out_stride) {
+    extern __shared__ double lds_g[];
+    // (selected with wave-uniform moves: indexing the by-value argument with blockIdx.y makes the compiler spill the whole table to scratch)
+    const int y = blockIdx.y;
+    hg::GaussParams G = M.g[0];
+    if (y == 1) G = M.g[1];
+    if (y == 2) G = M.g[2];
+    if (y == 3) G = M.g[3];
+    static_assert(hg::kGaussMaxMulti == 4, "selection above");
+    hg::gauss_rows_wg<T, R>(x, ldx, n, (int64_t)blockIdx.x * R, G, lds_g, out_reg + (int64_t)blockIdx.y * out_stride, nullptr);
 }
 
 template <typename F>
@@ -208,6 +230,52 @@ int hg_gauss_regression_device(hg_gauss* g, const void* x, int x_dtype, int64_t 
         if (n > 0 && (!x || !out_reg)) hg::fail(HG_ERR_ARG, "null data pointer");
         HG_HIP(hipSetDevice(g->device));
         launch(g, x, x_dtype, n, ldx, out_reg, out_std, (hipStream_t)stream);
+    });
+    if (rc != HG_OK) hg::set_last_error(g_gauss_error);
+    return rc;
+}
+
+int hg_gauss_regression_multi_device(hg_gauss* const* gs, int m, const void* x, int x_dtype, int64_t n, int64_t ldx, double* out_reg,
+                                     int64_t out_stride, void* stream) {
+    int rc = guarded([&] {
+        if (!gs || m < 1 || m > hg::kGaussMaxMulti) hg::fail(HG_ERR_ARG, "1..%d classifiers per launch", hg::kGaussMaxMulti);
+        if (n < 0 || n > 0x7fffffffll) hg::fail(HG_ERR_ARG, "bad row count");
+        if (out_stride < n) hg::fail(HG_ERR_ARG, "out_stride %lld < n %lld", (long long)out_stride, (long long)n);
+        if (x_dtype != HG_F32 && x_dtype != HG_F64) hg::fail(HG_ERR_ARG, "feature dtype must be HG_F32 or HG_F64");
+        bool wg = getenv("HIGSFA_GAUSS_WAVE") == nullptr, r4 = n >= 256;
+        size_t kd_max = 0;
+        for (int s = 0; s < m; ++s) {
+            if (!gs[s]) hg::fail(HG_ERR_ARG, "null classifier handle");
+            if (gs[s]->device != gs[0]->device) hg::fail(HG_ERR_ARG, "classifiers of one launch must live on one device");
+            if (ldx < gs[s]->d) hg::fail(HG_ERR_DIM, "x has %lld columns but a classifier's input_dim is %d", (long long)ldx, gs[s]->d);
+            const size_t kd = (size_t)gs[s]->K * gs[s]->d;
+            kd_max = std::max(kd_max, kd);
+            wg = wg && kd <= 4096;
+            r4 = r4 && kd <= 1536;
+        }
+        if (n > 0 && (!x || !out_reg)) hg::fail(HG_ERR_ARG, "null data pointer");
+        HG_HIP(hipSetDevice(gs[0]->device));
+        if (n == 0) return;
+        if (!wg || m == 1) {      // shapes the workgroup form does not take: one launch per classifier
+            for (int s = 0; s < m; ++s) launch(gs[s], x, x_dtype, n, ldx, out_reg + (int64_t)s * out_stride, nullptr, (hipStream_t)stream);
+            return;
+        }
+        GaussMulti M;
+        for (int s = 0; s < m; ++s) M.g[s] = hg::gauss_params(gs[s]);
+        const int R = r4 ? 4 : 1;
+        const size_t lds = (size_t)R * (64 + kd_max) * 8;
+        const dim3 grid((unsigned)((n + R - 1) / R), (unsigned)m);
+        hipStream_t st = (hipStream_t)stream;
+#define HG_GAUSS_WGM(TT, RR) hipLaunchKernelGGL((k_gauss_regression_wg_multi<TT, RR>), grid, dim3(256), lds, st, (const TT*)x, ldx, n, M, out_reg, out_stride)
+        if (x_dtype == HG_F32) {
+            if (r4) HG_GAUSS_WGM(float, 4);
+            else HG_GAUSS_WGM(float, 1);
+        } else {
+            if (r4) HG_GAUSS_WGM(double, 4);
+            else HG_GAUSS_WGM(double, 1);
+        }
+#undef HG_GAUSS_WGM
+        HG_HIP(hipGetLastError());
     });
     if (rc != HG_OK) hg::set_last_error(g_gauss_error);
     return rc;

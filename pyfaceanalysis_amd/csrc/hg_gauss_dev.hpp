@@ -9,6 +9,7 @@
 namespace hg {
 
 constexpr int kGaussMaxClasses = 1024;
+constexpr int kGaussMaxMulti = 4;      // classifiers per hg_gauss_regression_multi_device launch
 
 // What a classifier handle holds on the device (hg_gauss.hip): logw[c] = log p_c - log sqrtdet_c
 struct GaussParams {

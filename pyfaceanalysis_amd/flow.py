@@ -135,6 +135,14 @@ class Flow(object):
         """Plan listing (role of more_nodes.describe_flow, FaceDetectUpdated.py:193)."""
         return self._handle(nodenr).describe()
 
+    def host_transport(self, nodenr=None):
+        """How the last ``execute`` on host rows reached the device: 1 = packer threads stored straight into device memory (large
+        BAR and every input buffer confirmed host-mapped by hsa_amd_pointer_info), 0 = pinned ring + copy queues, -1 = no host call
+        yet (hg_flow_host_transport)."""
+        t = C.c_int(-1)
+        _capi.check(_capi.lib().hg_flow_host_transport(self._handle(nodenr).h, C.byref(t)))
+        return t.value
+
     def host_plan(self):
         """Parse + plan on the host only (works without a GPU): returns hg_info."""
         h = _Handle(self.to_blob(), self.force_generic)

@@ -69,6 +69,11 @@ AWKWARD = {
                                         ("Disc5", True, 9), ("Disc7", False, 9), ("Disc9", True, 9)],
     "two_disc_then_reuse": [("Disc1", True, 9), ("Disc3", False, 9), ("Disc5", False, 9), ("PosX0", True, 10), ("PAng0", False, 10),
                             ("Scale0", True, 10), ("Disc7", False, 9), ("PosY0", False, 10), ("Disc9", True, 9), ("PosX1", True, 10)],
+    # round 5 (stage groups: a network stage and the None stages behind it run as one regression launch + one glue launch, at most
+    # four stages): seven stages on ONE sl — the second group's first stage is a None stage NOT preceded by a network stage of its
+    # own group — with Disc stages inside both groups (their survivor counts must still reach the host)
+    "long_run_on_one_sl": [("Disc1", True, 9), ("PosX0", True, 10), ("PosY0", False, 10), ("Disc3", False, 9), ("PAng0", False, 10),
+                           ("Scale0", False, 10), ("PosX1", False, 10), ("Disc5", False, 9), ("Disc7", True, 9), ("PosY1", False, 10), ("Disc9", True, 9)],
 }
 
 
@@ -134,6 +139,19 @@ def test_device_cascade_matches_restated_loop(native_lib, nets, sequence):
     assert np.allclose(got["confidence"], ref["confidence"], rtol=1e-12, atol=1e-12)
     if any(s.type == "PAng" for s in stages[:-1]):
         assert np.abs(got["angles"]).max() > 0       # rotated extraction really took part
+    # stage groups against one launch pair per stage (HIGSFA_CASCADE_NO_GROUPS, read per frame), and the device-computed grid
+    # against windows handed over by the host: the same survivors with the same bits, the same counts wherever both report one
+    import os
+    os.environ["HIGSFA_CASCADE_NO_GROUPS"] = "1"
+    try:
+        single = dc.detect(torch.from_numpy(frame).cuda(), smallest_face=0.3, windows=(boxes, level))
+    finally:
+        del os.environ["HIGSFA_CASCADE_NO_GROUPS"]
+    for key in ("coords", "angles", "orig_index", "confidence"):
+        assert np.array_equal(single[key], got[key]), key
+    assert all(a == b for a, b in zip(single["counts"], got["counts"]) if a >= 0 and b >= 0) and single["rows_executed"] == got["rows_executed"]
+    assert sum(c >= 0 for c in got["counts"]) >= sum(c >= 0 for c in single["counts"])      # a group reports every stage's count
+    assert [c for c in got["counts"] if c >= 0] == [ref["counts"][i] for i, c in enumerate(got["counts"]) if c >= 0]
     # several frames' worth of windows in ONE batch (the glue kernel was one workgroup): the frame's windows repeated
     # until there are more than 20 000 — first stages on the multi-workgroup glue (mark + scatter), later ones on the single
     # workgroup — must give the single batch's survivors once per copy, in order, bit for bit
@@ -153,6 +171,70 @@ def test_device_cascade_matches_restated_loop(native_lib, nets, sequence):
     dc.close()
     for f in flows:
         f.close()
+
+
+@pytest.mark.gpu
+def test_device_grid_equals_host_grid(native_lib):
+    """hg_cascade_grid_device (the first-stage windows from the grid's closed form, face_analysis.py:630-669) against
+    grid.frame_boxes / cascade.frame_windows — numpy.linspace and the reference's box formula — bit for bit, on the configs[2]
+    frame, on the shipped pipeline's 64x64 windows, on a frame barely larger than one window and on a single-column grid."""
+    import ctypes as C
+    import torch
+    from pyfaceanalysis_amd import _capi
+    from pyfaceanalysis_amd.cascade import frame_levels, frame_windows
+    L = _capi.lib()
+    cases = [(1000, 562, 0.1, (128, 128)), (1000, 562, 0.2, (64, 64)), (1920, 1080, 0.05, (64, 64)), (160, 90, 0.3, (16, 16)),
+             (133, 131, 0.9, (128, 128)), (40, 400, 0.5, (32, 32)), (3648, 2736, 0.02, (64, 64))]
+    for fw, fh, sf, sub in cases:
+        boxes, level = frame_windows(fw, fh, sf, grid.FACE_PIPELINE, sub)
+        levels, n_levels, n0 = frame_levels(fw, fh, sf, grid.FACE_PIPELINE, sub)
+        assert n0 == len(boxes) > 0, (fw, fh, sf, sub)
+        n = C.c_int64()
+        _capi.check(L.hg_cascade_grid_device(0, levels, n_levels, None, None, 0, C.byref(n), None))
+        assert n.value == n0
+        b_dev = torch.empty((n0, 4), dtype=torch.float64, device="cuda")
+        l_dev = torch.empty((n0, 3), dtype=torch.float64, device="cuda")
+        _capi.check(L.hg_cascade_grid_device(0, levels, n_levels, C.c_void_p(b_dev.data_ptr()), C.c_void_p(l_dev.data_ptr()), n0, C.byref(n),
+                                             C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        torch.cuda.synchronize()
+        assert np.array_equal(b_dev.cpu().numpy(), boxes), (fw, fh, sf, sub)
+        assert np.array_equal(l_dev.cpu().numpy(), level), (fw, fh, sf, sub)
+    with pytest.raises(ValueError):
+        _capi.check(L.hg_cascade_grid_device(0, levels, 0, None, None, 0, C.byref(n), None))
+
+
+@pytest.mark.gpu
+def test_multi_classifier_regression_equals_single_launches(native_lib):
+    """hg_gauss_regression_multi_device (the regressions of a stage group in one launch) against one
+    hg_gauss_regression_device call per classifier: the same bits, for the class / width mix of the pipeline's groups
+    (10 x 9 Disc, 50 x 10 / 50 x 20 pose regressors), below and above the four-rows-per-workgroup threshold, F32 and F64 rows."""
+    import ctypes as C
+    import torch
+    from pyfaceanalysis_amd import _capi, synth_cascade
+    L = _capi.lib()
+    rng = np.random.default_rng(5)
+    feats = rng.normal(size=(600, 20))
+    clfs = [synth_cascade.quantile_classifier(feats, 10, np.linspace(-1, 1, 50)), synth_cascade.quantile_classifier(feats, 20, np.linspace(-3, 2, 50)),
+            synth_cascade.quantile_classifier(feats, 9, (np.arange(10) + 0.5) / 10), synth_cascade.quantile_classifier(feats, 20, np.linspace(0.8, 0.85, 50))]
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for n in (1, 7, 255, 256, 1031):
+        for dt, code in ((torch.float32, _capi.HG_F32), (torch.float64, _capi.HG_F64)):
+            x = torch.from_numpy(rng.normal(size=(n, 24))).to(dt).cuda()
+            for m in (1, 2, 4):
+                hs = (C.c_void_p * m)(*[c._handle(c.avg_labels) for c in clfs[:m]])
+                multi = torch.full((m, n + 5), np.nan, dtype=torch.float64, device="cuda")
+                _capi.check(L.hg_gauss_regression_multi_device(hs, m, C.c_void_p(x.data_ptr()), code, n, 24, C.c_void_p(multi.data_ptr()), n + 5, st))
+                for s in range(m):
+                    one = torch.empty(n, dtype=torch.float64, device="cuda")
+                    _capi.check(L.hg_gauss_regression_device(hs[s], C.c_void_p(x.data_ptr()), code, n, 24, C.c_void_p(one.data_ptr()), None, st))
+                    torch.cuda.synchronize()
+                    assert np.array_equal(multi[s, :n].cpu().numpy(), one.cpu().numpy()), (n, dt, m, s)
+                    assert bool(torch.isnan(multi[s, n:]).all())
+    hs = (C.c_void_p * 5)(*[clfs[0]._handle(clfs[0].avg_labels)] * 5)
+    with pytest.raises(ValueError):
+        _capi.check(L.hg_gauss_regression_multi_device(hs, 5, C.c_void_p(x.data_ptr()), code, 1, 24, C.c_void_p(multi.data_ptr()), 8, st))
+    for c in clfs:
+        c.close()
 
 
 @pytest.mark.gpu
@@ -197,6 +279,11 @@ def test_config3_full_pyramid_1080p(native_lib, nets):
     dc = DeviceCascade(stages, (128, 128), 20, pipe)
     got = dc.detect(small_dev, smallest_face=0.1)
     assert got["n_windows"] == 1738 and got["counts"][0] < 600 and got["rows_executed"] >= 1738
+    # prescale + grid + stage loop as one host call (what bench.py times): the same answer from the full-size frame
+    whole = dc.detect_frame(fdev, smallest_face=0.1)
+    assert whole["n_windows"] == 1738 and list(whole["counts"]) == list(got["counts"]) and whole["rows_executed"] == got["rows_executed"]
+    for key in ("coords", "angles", "orig_index", "confidence"):
+        assert np.array_equal(whole[key], got[key]), key
 
     def extract(coords, dang):
         return pt.extract(small, coords, (128, 128), dtype=np.uint8, delta_angs=dang) if len(coords) else np.zeros((0, 16384), np.uint8)

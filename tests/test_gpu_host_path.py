@@ -89,6 +89,32 @@ def test_u11l_host_path_all_dtypes(native_lib, nets, monkeypatch, direct):
     flow.close()
 
 
+def test_direct_stores_only_into_confirmed_host_mapped_buffers(native_lib, nets, monkeypatch):
+    """the packers store into a pass's input buffer only after hsa_amd_pointer_info has confirmed THAT
+    allocation host-mapped at its device address; any other answer — forced here with HIGSFA_HOST_PROBE_DENY, read per probe —
+    selects the pinned ring, with the same bits.  On a box whose device has no large BAR both calls take the ring."""
+    nodes = nets("T5L-16")
+    x = synth.make_subimages(9000, 16, dtype=np.float64)
+    flow = Flow(nodes)
+    assert flow.host_transport() == -1
+    y = flow.execute(x)
+    t_default = flow.host_transport()
+    assert t_default in (0, 1)
+    monkeypatch.setenv("HIGSFA_HOST_PROBE_DENY", "1")
+    denied = Flow(nodes)                      # fresh handle: fresh buffers, probed under the denial
+    yd = denied.execute(x)
+    assert denied.host_transport() == 0
+    assert np.array_equal(yd, y)
+    monkeypatch.delenv("HIGSFA_HOST_PROBE_DENY")
+    assert np.array_equal(denied.execute(x[:4000]), y[:4000]) and denied.host_transport() == 0      # the answer is kept per allocation
+    # both transports on a call with several passes and a narrowing fall-through in the middle
+    xf = x.copy()
+    xf[5000, 3] = 0.5
+    assert np.array_equal(denied.execute(xf), flow.execute(xf)) and flow.host_transport() == t_default
+    flow.close()
+    denied.close()
+
+
 def test_sharded_c_entry_on_replicas(native_lib, nets):
     """hg_flow_execute_sharded with the one visible GPU listed two and three times: every listed entry is a replica
     with its own weights, streams and staging, the row blocks run concurrently from separate host threads and land
