@@ -32,6 +32,7 @@ SIDE = 128
 PRESET = "U11L-128"
 PEAK_MFMA_F32_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0
+PEAK_MFMA_F64_TFLOPS = 78.6      # MI355X data sheet: FP64 matrix = FP64 vector = half the FP32 rate above (the guide lists no fp64 row)
 TRAFFIC_PROFILE = "r04_traffic.json"   # committed PMC summary the roofline's `traffic` is read from
 
 
@@ -66,10 +67,20 @@ def cpu_baseline(nodes, n=256, reps=6):
                               "best of 3 after 1 warm-up" % t12}
     except Exception:
         pass
-    out = {"value": n / best, "unit": "sub-images/s", "cores": threads, "kind": "port",
+    quota = None
+    try:      # cgroup v2 CPU quota of this container ("max" = none)
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
+    avail = len(os.sched_getaffinity(0))
+    cpus_available = int(min(avail, quota)) if quota else avail
+    out = {"value": n / best, "unit": "sub-images/s", "cores": min(threads, cpus_available), "kind": "port",
+           "cpus_available": cpus_available, "cpu_affinity": avail, "cpu_quota": quota, "blas_threads": threads,
            "sample": "%d sub-images of 128x128 float64 through oracle/mdp_restate.py (MDP-structured numpy "
                      "restatement: per-node Python loop + numpy.dot), best of %d passes after 1 warm-up; "
-                     "numpy BLAS threads=%d" % (n, reps, threads)}
+                     "numpy BLAS pool %d threads on %d CPUs available to this process (affinity %d, cgroup quota %s)"
+                     % (n, reps, threads, cpus_available, avail, "none" if quota is None else "%.0f" % quota)}
     if at12 is not None:
         out["blas_12_threads"] = at12
     # the "good CPU" point: the same flow from one flat op list in C, float64, row chunks
@@ -235,17 +246,27 @@ def host_path_leg(blob):
     hg_flow_execute — packers narrowing / copying rows straight into device memory, passes sized by the planner, features
     back, synchronous — on float64 (what images_asarray yields), float32 and uint8 batches of 4096 and 728 rows (728 = the
     largest single execute of a real 1080p frame).  Best and median of 9 after two warm-up calls.
-    Beside every figure the ceiling that bounds it and the fraction reached: the host reading the caller's array
-    (float64 / float32: `host_read_GBps`, measured by tools/ubench/host_pack_bw.cpp: 16 threads on the rows' memory node
-    narrow float64 at 288 GB/s) or host stores into device memory over PCIe (`link_GBps`: 43 GB/s through the BAR,
-    tools/ubench/bar_write_bw.cpp) for the 16 KiB a row occupies on the wire.  `caller_GBps` = bytes of the caller's array
-    per second (float rows holding integer pixel values cross PCIe as uint8 after the exact narrowing, so this is NOT the
-    PCIe rate)."""
-    from pyfaceanalysis_amd import synth
+    Beside every figure the ceiling that bounds it, MEASURED in this process on this box (round 5; rounds 3-4 used constants
+    from a micro-benchmark on another box, and one call beat its "ceiling"): `pack_ms` — the library's packer threads alone over
+    the very array of the call (hg_host_pack_probe: same pool, placement and routines, destinations in cache), i.e. how fast
+    this host reads and narrows these rows; `wire_ms` — the call's wire bytes (16 KiB per row: float rows holding integer
+    pixel values cross PCIe as uint8 after the exact narrowing) at the FASTER of host stores into device memory
+    (hg_host_store_probe, six writers as in the call) and a pinned copy-engine transfer (hg_host_dma_probe), 64 MiB each.
+    `ceiling_ms` = max(pack_ms, wire_ms); `frac_of_ceiling` = ceiling_ms / ms_per_call.  `caller_GBps` = bytes of the
+    caller's array per second (NOT the PCIe rate)."""
+    import ctypes as C
+    from pyfaceanalysis_amd import _capi, synth
     from pyfaceanalysis_amd.flow import Flow
-    host_read, link = 288.0, 43.0
+    L = _capi.lib()
     out = {}
     f = Flow.from_blob(blob, output_dtype=np.float64)
+    probe_bytes = 64 << 20
+    t_store, t_dma, direct = C.c_double(), C.c_double(), C.c_int()
+    _capi.check(L.hg_host_store_probe(0, probe_bytes, 5, C.byref(t_store), C.byref(direct)))
+    _capi.check(L.hg_host_dma_probe(0, probe_bytes, 5, C.byref(t_dma)))
+    store_GBps = probe_bytes / t_store.value / 1e9 if direct.value and t_store.value > 0 else None
+    dma_GBps = probe_bytes / t_dma.value / 1e9
+    link = max(store_GBps or 0.0, dma_GBps)
     for dt in (np.float64, np.float32, np.uint8):
         for n in (4096, 728):
             x = synth.make_subimages(n, SIDE, dtype=dt)
@@ -257,16 +278,18 @@ def host_path_leg(blob):
                 f.execute(x, n_cols=N_COLS)
                 ts.append(time.perf_counter() - t0)
             best, med = min(ts), sorted(ts)[len(ts) // 2]
-            t_read = x.nbytes / (host_read * 1e9) if dt != np.uint8 else 0.0
+            t_pack = C.c_double()
+            _capi.check(L.hg_host_pack_probe(x.ctypes.data_as(C.c_void_p), _capi.np_dtype_code(x.dtype), n, x.shape[1], x.shape[1], 9, C.byref(t_pack)))
             t_link = n * SIDE * SIDE / (link * 1e9)
-            floor = max(t_read, t_link)
+            floor = max(t_pack.value, t_link)
             out["%s_n%d" % (np.dtype(dt).name, n)] = {
                 "sub_images_per_s": n / best, "ms_per_call": best * 1e3, "ms_per_call_median": med * 1e3, "caller_GBps": x.nbytes / best / 1e9,
-                "wire_GBps": n * SIDE * SIDE / best / 1e9, "ceiling": "host read" if t_read >= t_link else "PCIe (host stores into device memory)",
-                "ceiling_ms": floor * 1e3, "frac_of_ceiling": floor / best}
+                "wire_GBps": n * SIDE * SIDE / best / 1e9, "pack_ms": t_pack.value * 1e3, "pack_GBps": x.nbytes / t_pack.value / 1e9,
+                "wire_ms": t_link * 1e3, "ceiling": "host packers (read + narrow)" if t_pack.value >= t_link else "PCIe (faster of BAR stores and pinned DMA)",
+                "ceiling_ms": floor * 1e3, "frac_of_ceiling": floor / best, "transport": {1: "direct stores", 0: "pinned ring"}.get(f.host_transport(), "?")}
     f.close()
-    out["ceilings"] = {"host_read_GBps": host_read, "link_GBps": link,
-                       "source": "tools/ubench/host_pack_bw.cpp, tools/ubench/bar_write_bw.cpp (profiles/r04_host_path.txt)"}
+    out["ceilings"] = {"bar_store_GBps": store_GBps, "pinned_dma_GBps": dma_GBps, "link_GBps_used": link, "probe_bytes": probe_bytes,
+                       "source": "measured in this process: hg_host_store_probe / hg_host_dma_probe (64 MiB, best of 5), hg_host_pack_probe per case (best of 9)"}
     out["note"] = "Flow.execute(host ndarray) -> host float64 (N, 20): includes packing, PCIe, kernels, features back; never `value`"
     return out
 
@@ -345,6 +368,14 @@ def train_leg(dev, n=100_000):
     return {"workload": "configs[4]: %d patches of 128x128 uint8 resident in HBM, 1024 nodes x 16 inputs" % n, "statistics_ms": best[0],
             "eigensolve_ms": best[1], "wall_ms": best[2], "input_GBps": n * SIDE * SIDE / best[0] / 1e6,
             "statistics_gflops_f64": n * 1024.0 * (16 * 16 * 2) * 2 / best[0] / 1e6,
+            # the two roofs of the statistics kernel: HBM for the patch read (MI355X_MICROARCH.md: 8 TB/s), the fp64 matrix rate for the
+            # products as ISSUED — both 16 x 16 products (covariance, covariance of the differences) in full, although each is symmetric
+            "roofline": {"hbm": {"achieved_GBps": n * SIDE * SIDE / best[0] / 1e6, "peak_GBps": PEAK_HBM_GBS, "frac": n * SIDE * SIDE / best[0] / 1e6 / PEAK_HBM_GBS},
+                         "mfma_f64": {"achieved_TFLOPs": n * 1024.0 * (16 * 16 * 2) * 2 / best[0] / 1e9, "peak_TFLOPs": PEAK_MFMA_F64_TFLOPS,
+                                      "frac": n * 1024.0 * (16 * 16 * 2) * 2 / best[0] / 1e9 / PEAK_MFMA_F64_TFLOPS,
+                                      "peak_source": "MI355X data sheet FP64 matrix = FP64 vector rate, half the FP32 rate of MI355X_MICROARCH.md (157.3)",
+                                      "symmetric_half_TFLOPs": n * 1024.0 * (16 * 17) * 2 / best[0] / 1e9},
+                         "bound": "neither: 1.64 GB of uint8 patches widened to fp64 in registers, 16 patch columns per node"},
             "max_rel_err_eigenvalues_vs_scipy": worst_val, "max_err_eigenvectors_vs_scipy": worst_vec, "nodes_checked": 3, "budget": 1e-5}
 
 
@@ -424,6 +455,11 @@ def main():
     ap.add_argument("--no-inflight", action="store_true", help="skip the batches-in-flight figure")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip host_path / u11l_64 / train_leg / uniform_input (figures beside the headline, outside the timed region)")
+    ap.add_argument("--gather-stream", default="side", choices=["side", "same"],
+                    help="distributed path: the all-gather on a side stream under the next step's kernels (default) or on the kernels' own stream")
+    ap.add_argument("--compare-collective", action="store_true",
+                    help="distributed path: after the headline, time the same step collective-free, with the side-stream gather and with the "
+                         "same-stream gather in THIS process (collective_compare in the line; VERDICT r4 item 3)")
     ap.add_argument("--node-kind", default="pca_exp_sfa", choices=["pca_exp_sfa", "igsfa"],
                     help="node type of the synthetic 11-layer net (default: the BASELINE.md workload)")
     args = ap.parse_args()
@@ -486,16 +522,23 @@ def main():
         # between ranks (x is rank-seeded), every rank comparing every rank's block.  First with the device-scope hand-off event
         # (3-4 us per step cheaper); if any rank sees a mismatch, all ranks fall back to the ordinary event and check again.
         x_alts = [x, torch.roll(x, shifts=1 + rank, dims=0), torch.flip(x, dims=(0,))]
-        sf = ShardedFlow.for_flow(flow, N_COLS, rows, dev, collective=True, light_events=True)
-        if sf.verify_against_blocking_gather(x_alts, steps=6):
-            gather_events = "device-scope hand-off event; 6 steps on changing inputs equal to a blocking all-gather on every rank"
-        else:
-            sf.close()
-            sf = ShardedFlow.for_flow(flow, N_COLS, rows, dev, collective=True, light_events=False)
+        light_ok = False
+        if args.gather_stream == "same":
+            sf = ShardedFlow.for_flow(flow, N_COLS, rows, dev, collective=True, gather_stream="same")
             if not sf.verify_against_blocking_gather(x_alts, steps=6):
-                raise SystemExit("bench.py: the overlapped all-gather does not reproduce a blocking one (rank %d)" % rank)
-            gather_events = "system-scope hand-off event (the device-scope form FAILED verification on this node)"
-        del x_alts
+                raise SystemExit("bench.py: the same-stream all-gather does not reproduce a blocking one (rank %d)" % rank)
+            gather_events = "all-gather on the kernels' own stream; 6 steps on changing inputs equal to a blocking all-gather on every rank"
+        else:
+            sf = ShardedFlow.for_flow(flow, N_COLS, rows, dev, collective=True, light_events=True)
+            if sf.verify_against_blocking_gather(x_alts, steps=6):
+                light_ok = True
+                gather_events = "device-scope hand-off event; 6 steps on changing inputs equal to a blocking all-gather on every rank"
+            else:
+                sf.close()
+                sf = ShardedFlow.for_flow(flow, N_COLS, rows, dev, collective=True, light_events=False)
+                if not sf.verify_against_blocking_gather(x_alts, steps=6):
+                    raise SystemExit("bench.py: the overlapped all-gather does not reproduce a blocking one (rank %d)" % rank)
+                gather_events = "system-scope hand-off event (the device-scope form FAILED verification on this node)"
     else:
         sf = ShardedFlow.for_flow(flow, N_COLS, rows, dev, collective=False)
     stream = sf.stream
@@ -546,6 +589,37 @@ def main():
         blocks = sf.y_alls[(sf._n - 1) & 1].view(world, rows, N_COLS)
         if not bool((blocks.abs().amax(dim=(1, 2)) > 0).all()) or (world > 1 and torch.equal(blocks[0], blocks[1])):
             raise SystemExit("bench.py: all-gather result misses a rank's block")
+    # --- the same step with and without the collective, in THIS process (--compare-collective; every rank runs every variant)
+    collective_compare = None
+    if distributed and args.compare_collective:
+        def timed_variant(sfv):
+            for _ in range(max(args.warmup, 100)):
+                sfv.step(x)
+            torch.cuda.synchronize(dev)
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                sfv.step(x)
+            torch.cuda.synchronize(dev)
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+            tt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item()) / args.steps * 1e3
+        collective_compare = {"order": [], "ms_per_step": []}
+        for name in ("collective_free", "side_stream", "same_stream", "collective_free", "side_stream", "same_stream"):
+            if name == "collective_free":
+                sfv = ShardedFlow.for_flow(flow, N_COLS, rows, dev, collective=False)
+            elif name == "side_stream":
+                sfv = ShardedFlow.for_flow(flow, N_COLS, rows, dev, collective=True, light_events=light_ok or args.gather_stream == "same")
+            else:
+                sfv = ShardedFlow.for_flow(flow, N_COLS, rows, dev, collective=True, gather_stream="same")
+            if sfv.collective and not sfv.verify_against_blocking_gather(x_alts, steps=4):
+                raise SystemExit("bench.py: %s does not reproduce a blocking all-gather (rank %d)" % (name, rank))
+            collective_compare["order"].append(name)
+            collective_compare["ms_per_step"].append(round(timed_variant(sfv), 5))
+            sfv.close()
     y = sf.ys[(sf._n - 1) & 1]
     y_prof = torch.empty((rows, N_COLS), dtype=torch.float32, device=dev)
 
@@ -560,6 +634,10 @@ def main():
         prof_steps = max(5, min(11, args.steps))
         samples, names = [], []
         for _ in range(prof_steps):      # one sample per pass; the median drops a pass hit by a host hiccup
+            # every profiled pass ends in a synchronisation and a read-back: without load in between the chip's clock sags and the event
+            # times read 10-12 % long (seen in round 4's torchrun world-1 line and again in round 5) — 20 plain steps keep it up
+            for _ in range(20):
+                flow.execute_device(x.data_ptr(), in_dt, rows, x.shape[1], y_prof.data_ptr(), np.float32, N_COLS, N_COLS, stream=stream.cuda_stream)
             _capi.check(L.hg_flow_reset_profile(h.h))
             flow.execute_device(x.data_ptr(), in_dt, rows, x.shape[1], y_prof.data_ptr(), np.float32, N_COLS, N_COLS,
                                 stream=stream.cuda_stream, profile=True)
@@ -690,7 +768,7 @@ def main():
             "config": {"workload": "configs[1]: U11L-128 (11-layer net, " + ("iGSFA nodes, " if args.node_kind == "igsfa" else "") + "trained random-init weights), "
                                    "%d synthetic 128x128 sub-images per GPU per step, %s input resident in HBM, "
                                    "first %d slow features out%s" % (rows, in_dt.name, N_COLS,
-                                                                     ", RCCL all-gather of the features overlapped with the next step" if distributed else ""),
+                                                                     (", RCCL all-gather of the features " + ("on the kernels' stream" if args.gather_stream == "same" else "overlapped with the next step")) if distributed else ""),
                        "settle_ms": round(settle_ms, 1), "rows_per_gpu": rows, "global_rows": total_rows, "plan": "fused" if info.plan_kind == 1 else "generic",
                        "parallelism": "row-shard x%d" % world, **({"gather_events": gather_events} if gather_events else {})},
             "max_rel_err_vs_oracle": max_rel,
@@ -703,6 +781,8 @@ def main():
         }
         if in_flight is not None:
             out["batches_in_flight"] = in_flight
+        if collective_compare is not None:
+            out["collective_compare"] = collective_compare
         if not args.no_frame and world == 1 and info.plan_kind == 1 and args.node_kind == "pca_exp_sfa":
             try:
                 fr = frame_leg(flow, dev, flow_factory=lambda: Flow.from_blob(blob, device=local_rank, output_dtype=np.float32))
@@ -727,6 +807,9 @@ def main():
             op = out["cpu_baseline"].get("optimised_port")
             if op and op.get("value"):      # the honest CPU point: flat float64 C port, AVX2 + OpenMP, on `cores` of the box's cores
                 out["speedup_vs_optimised_c_port"] = {"ratio": value / op["value"], "cores": op.get("cores")}
+        # a leg that failed left {"error": ...} under its key: named at the top level too (tools/run_gpu_suite.sh fails on it; the exit
+        # code stays 0 so that the headline of a run whose side leg broke is not lost — ADVICE r4)
+        out["legs_failed"] = [k for k, v in out.items() if isinstance(v, dict) and "error" in v]
         print(json.dumps(out), flush=True)
     flow.close()
     if distributed:

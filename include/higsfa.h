@@ -147,6 +147,15 @@ int hg_event_query(void* ev);
  * where the device reports a large BAR AND hsa_amd_pointer_info confirms every input buffer host-mapped at its device address;
  * 0 — pinned ring + copy queues (HIGSFA_HOST_DIRECT=0, or any other answer of the probe); -1 — no such call yet. */
 int hg_flow_host_transport(const hg_flow* f, int* transport);
+/* What bounds that call on THIS box, measured in the caller's process (bench.py puts them beside the host-path figures):
+ * hg_host_pack_probe — the library's packer threads alone over the caller's array (same pool, placement and routines as
+ * hg_flow_execute; destinations stay in cache): the rate at which the host can read and narrow / copy these rows;
+ * hg_host_store_probe — the packers storing `bytes` from host memory straight into device memory (*direct = 0 and no time where
+ * hg_flow_execute would not do that either); hg_host_dma_probe — one pinned-memory copy of `bytes` through the copy engine.
+ * best_seconds: best of `reps` rounds after one untimed round. */
+int hg_host_pack_probe(const void* x, int x_dtype, int64_t n, int64_t ldx, int64_t in_dim, int reps, double* best_seconds);
+int hg_host_store_probe(int device, size_t bytes, int reps, double* best_seconds, int* direct);
+int hg_host_dma_probe(int device, size_t bytes, int reps, double* best_seconds);
 /* Per-stage timing (the `benchmark=` kwarg of the reference call; benchmarking.py:39-58).
  * When enabled every stage launch is bracketed by hipEvents on the execution stream. */
 int hg_flow_set_profiling(hg_flow* f, int enabled);

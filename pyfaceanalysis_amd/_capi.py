@@ -86,6 +86,9 @@ def lib():
         "hg_stream_wait_event": (C.c_int, [vp, vp]),
         "hg_event_query": (C.c_int, [vp]),
         "hg_flow_host_transport": (C.c_int, [vp, C.POINTER(C.c_int)]),
+        "hg_host_pack_probe": (C.c_int, [vp, i32, i64, i64, i64, i32, C.POINTER(C.c_double)]),
+        "hg_host_store_probe": (C.c_int, [i32, sz, i32, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+        "hg_host_dma_probe": (C.c_int, [i32, sz, i32, C.POINTER(C.c_double)]),
         "hg_flow_set_profiling": (C.c_int, [vp, i32]),
         "hg_flow_stage_times": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(i64), i32, C.POINTER(i32)]),
         "hg_flow_stage_name": (C.c_int, [vp, i32, C.c_char_p, sz]),
@@ -125,7 +128,7 @@ def lib():
 EXPORTED_SYMBOLS = (
     "hg_version", "hg_last_error", "hg_device_count", "hg_flow_load", "hg_flow_free", "hg_flow_info",
     "hg_flow_describe", "hg_flow_to_device", "hg_flow_reserve", "hg_flow_execute", "hg_flow_execute_sharded",
-    "hg_flow_execute_device", "hg_event_create", "hg_event_create_on", "hg_event_destroy", "hg_event_record", "hg_stream_wait_event", "hg_event_query", "hg_flow_host_transport", "hg_flow_set_profiling", "hg_flow_stage_times", "hg_flow_stage_name",
+    "hg_flow_execute_device", "hg_event_create", "hg_event_create_on", "hg_event_destroy", "hg_event_record", "hg_stream_wait_event", "hg_event_query", "hg_flow_host_transport", "hg_host_pack_probe", "hg_host_store_probe", "hg_host_dma_probe", "hg_flow_set_profiling", "hg_flow_stage_times", "hg_flow_stage_name",
     "hg_flow_reset_profile", "hg_gauss_create", "hg_gauss_free", "hg_gauss_regression_device",
     "hg_gauss_regression", "hg_patcher_create", "hg_patcher_free", "hg_patcher_extract_device",
     "hg_patcher_extract", "hg_patcher_extract_rotate_device", "hg_patcher_extract_rotate", "hg_cascade_update_device",

@@ -835,6 +835,112 @@ int hg_event_query(void* ev) {
     return rc == HG_OK ? done : rc;
 }
 
+// ---- ceilings of the host path, MEASURED in the caller's process on the caller's box (bench.py host_path leg) ----
+// (1) the packers alone: the same pool, placement, ticket size and narrowing / copy routines as hg_flow_execute, destinations in a
+//     per-ticket scratch that stays in cache — the rate at which this host reads THIS array; (2) host stores into device memory
+//     (only where hg_flow_execute would use them: large BAR + host_can_store); (3) a pinned-memory copy engine transfer.
+int hg_host_pack_probe(const void* x, int x_dtype, int64_t n, int64_t ldx, int64_t in_dim, int reps, double* best_seconds) {
+    return guarded([&] {
+        if (!x || n <= 0 || in_dim <= 0 || ldx < in_dim || !best_seconds || reps < 1) hg::fail(HG_ERR_ARG, "bad argument");
+        if (x_dtype != HG_U8 && x_dtype != HG_F32 && x_dtype != HG_F64) hg::fail(HG_ERR_ARG, "bad dtype");
+        const size_t xs = hg::dtype_size(x_dtype), row_src = (size_t)ldx * xs;
+        HostPool* pool = &HostPool::get();
+        {
+            const int a = node_of_address(x), b = node_of_address((const char*)x + (size_t)(n - 1) * row_src + (size_t)in_dim * xs - 1);
+            pool->bind_to_node(a == b ? a : -1);
+        }
+        const size_t ticket_bytes = x_dtype == HG_U8 ? (size_t)128 << 10 : (size_t)512 << 10;      // as run_host_rows_impl
+        const int64_t ticket_rows = std::max<int64_t>(1, (int64_t)(ticket_bytes / ((size_t)in_dim * xs)));
+        const int n_tickets = (int)((n + ticket_rows - 1) / ticket_rows);
+        std::atomic<int> bad{0};
+        const std::function<void(int)> ticket = [&](int t) {
+            thread_local std::vector<uint8_t> scratch;
+            if (scratch.size() < (size_t)in_dim * xs) scratch.resize((size_t)in_dim * xs);
+            const int64_t a = (int64_t)t * ticket_rows, e = std::min(n, a + ticket_rows);
+            const char* src = (const char*)x + (size_t)a * row_src;
+            for (int64_t r = a; r < e; ++r, src += row_src) {
+                bool ok = true;
+                if (x_dtype == HG_F64) ok = hg::narrow_row_f64((const double*)src, scratch.data(), in_dim);
+                else if (x_dtype == HG_F32) ok = hg::narrow_row_f32((const float*)src, scratch.data(), in_dim);
+                else memcpy(scratch.data(), src, (size_t)in_dim);
+                if (!ok) bad.fetch_add(1, std::memory_order_relaxed);
+            }
+        };
+        double best = 1e30;
+        for (int rep = 0; rep < reps + 1; ++rep) {      // one untimed round first
+            const auto t0 = std::chrono::steady_clock::now();
+            pool->parallel_for(n_tickets, ticket);
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (rep > 0) best = std::min(best, dt);
+        }
+        *best_seconds = best;
+    });
+}
+
+int hg_host_store_probe(int device, size_t bytes, int reps, double* best_seconds, int* direct) {
+    return guarded([&] {
+        if (!best_seconds || !direct || bytes < ((size_t)1 << 20) || reps < 1) hg::fail(HG_ERR_ARG, "bad argument");
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) hg::fail(HG_ERR_DEVICE, "no such device");
+        HG_HIP(hipSetDevice(device));
+        int lb = 0;
+        const bool large_bar = hipDeviceGetAttribute(&lb, hipDeviceAttributeIsLargeBar, device) == hipSuccess && lb != 0;
+        hg::DevBuf dst;
+        dst.alloc(bytes);
+        *direct = (large_bar && host_can_store(dst.p, bytes)) ? 1 : 0;
+        *best_seconds = 0.0;
+        if (!*direct) return;
+        std::vector<uint8_t> src(bytes);
+        for (size_t i = 0; i < bytes; i += 4096) src[i] = (uint8_t)(i >> 12);
+        HostPool* pool = &HostPool::get();
+        pool->bind_to_node(node_of_address(src.data()));
+        const size_t piece = (size_t)128 << 10;
+        const int n_tickets = (int)((bytes + piece - 1) / piece);
+        const std::function<void(int)> ticket = [&](int t) {
+            const size_t o = (size_t)t * piece, m = std::min(piece, bytes - o);
+            hg::stream_copy((uint8_t*)dst.p + o, src.data() + o, m);
+            hg::store_fence();
+        };
+        double best = 1e30;
+        for (int rep = 0; rep < reps + 1; ++rep) {
+            const auto t0 = std::chrono::steady_clock::now();
+            pool->begin(n_tickets, ticket, 6);      // the writers run_host_rows_impl uses for rows that are only copied
+            pool->end();
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (rep > 0) best = std::min(best, dt);
+        }
+        *best_seconds = best;
+    });
+}
+
+int hg_host_dma_probe(int device, size_t bytes, int reps, double* best_seconds) {
+    return guarded([&] {
+        if (!best_seconds || bytes < ((size_t)1 << 20) || reps < 1) hg::fail(HG_ERR_ARG, "bad argument");
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) hg::fail(HG_ERR_DEVICE, "no such device");
+        HG_HIP(hipSetDevice(device));
+        hg::DevBuf dst;
+        dst.alloc(bytes);
+        void* src = nullptr;
+        HG_HIP(hipHostMalloc(&src, bytes, hipHostMallocDefault));
+        memset(src, 1, bytes);
+        hipStream_t st = nullptr;
+        hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        double best = 1e30;
+        for (int rep = 0; rep < reps + 1 && e == hipSuccess; ++rep) {
+            const auto t0 = std::chrono::steady_clock::now();
+            e = hipMemcpyAsync(dst.p, src, bytes, hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (rep > 0) best = std::min(best, dt);
+        }
+        if (st) (void)hipStreamDestroy(st);
+        (void)hipHostFree(src);
+        HG_HIP(e);
+        *best_seconds = best;
+    });
+}
+
 int hg_flow_host_transport(const hg_flow* f, int* transport) {
     return guarded([&] {
         if (!f || !transport) hg::fail(HG_ERR_ARG, "null argument");

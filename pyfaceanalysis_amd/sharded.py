@@ -65,6 +65,9 @@ class ShardedFlow(object):
     ``wait()`` has returned or ``done_event(i)`` of that step has been waited for, and ONLY until step
     i + 2 is enqueued, which writes the same buffer again: a consumer that needs it longer copies it.
 
+    ``gather_stream``: "side" (default) as described above; "same": the collective is enqueued behind the kernels on their own
+    stream — no hand-off between two queues, but the gather's time is no longer hidden under the next step's kernels.
+
     ``light_events``: scope of the event that hands a step's features from the kernels to the collective.  False (the
     default, also ``HIGSFA_GATHER_LIGHT_EVENTS=0`` / unset): an ordinary event, whose record publishes the kernels' writes
     to system scope — what any transport of the collective may rely on.  True: a device-scope event
@@ -75,7 +78,7 @@ class ShardedFlow(object):
     ("the gather has finished READING buffer b": an order, no data) are always device-scope.
     """
 
-    def __init__(self, execute_local, n_cols, rows, device=None, collective=None, light_events=None):
+    def __init__(self, execute_local, n_cols, rows, device=None, collective=None, light_events=None, gather_stream="side"):
         import torch
         import torch.distributed as dist
         self.torch = torch
@@ -94,12 +97,15 @@ class ShardedFlow(object):
         self.y_alls = [mk(self.rows * self.world), mk(self.rows * self.world)] if self.collective else None
         self._n = 0
         self._filled = [0, 0]          # rows of ys[b] that may hold features of an earlier step
+        if gather_stream not in ("side", "same"):
+            raise ValueError("gather_stream must be 'side' or 'same'")
+        self.gather_stream = gather_stream
         if self.cuda:
             self.stream = torch.cuda.current_stream(self.device)
-            self.comm = _side_stream(torch, self.device) if self.collective else None
+            self.comm = _side_stream(torch, self.device) if (self.collective and gather_stream == "side") else None
             self.gathered = [torch.cuda.Event(), torch.cuda.Event()]     # for the caller (done_event): recorded on the side stream
             self._light = None
-            if self.collective:
+            if self.collective and gather_stream == "side":
                 # events ordering the two streams against each other: [0/1] "gather of buffer b enqueued so far is done"
                 # (side stream -> kernels; a read-before-overwrite order, device scope), [2] "kernels of this step are done"
                 # (kernels -> side stream; carries the features: scope chosen by light_events).  Created on self.device,
@@ -119,7 +125,7 @@ class ShardedFlow(object):
                 self._recorded = [False, False]
 
     @classmethod
-    def for_flow(cls, flow, n_cols, rows, device, collective=None, light_events=None):
+    def for_flow(cls, flow, n_cols, rows, device, collective=None, light_events=None, gather_stream="side"):
         """Bind ``flow.execute_device`` (pyfaceanalysis_amd.flow.Flow on this rank's GPU)."""
         import numpy as np
         import torch
@@ -131,7 +137,7 @@ class ShardedFlow(object):
                 raise ValueError("ShardedFlow: x rows and the feature buffer must be contiguous")
             flow.execute_device(x_block.data_ptr(), np_dt[x_block.dtype], x_block.shape[0], x_block.stride(0),
                                 y_out.data_ptr(), np.float32, n_cols, n_cols, stream=stream)
-        return cls(run, n_cols, rows, device=device, collective=collective, light_events=light_events)
+        return cls(run, n_cols, rows, device=device, collective=collective, light_events=light_events, gather_stream=gather_stream)
 
     def step(self, x_local):
         """Enqueue one pass over this rank's block; returns the (world*rows, n_cols) gathered features
@@ -160,6 +166,14 @@ class ShardedFlow(object):
             self.execute_local(x_local, self.ys[b][:m], self.stream.cuda_stream if self.cuda else 0)
         if not self.collective:
             return self.ys[b]
+        if self.cuda and self.gather_stream == "same":
+            # The collective on the kernels' OWN stream (round 5): no event, no second queue, nothing for the next
+            # step's first kernel to wait for but the gather itself, which is then serial with the kernels instead of hidden
+            # under the next step's (measured beside the side-stream form at world size 1: profiles/r05_rccl_world1.txt).
+            with torch.cuda.stream(self.stream):
+                gather_features(self.ys[b], self.y_alls[b])
+                self.gathered[b].record(self.stream)
+            return self.y_alls[b]
         if self.cuda:
             L = self._capi.lib()
             # The NEXT step writes ys[1 - b]; the gather that read it (last step's) must be done before.  It almost always is,

@@ -138,8 +138,12 @@ def test_collective_step_costs_no_more_than_collective_free(rccl_world1):
     rows = 4096
     x = torch.from_numpy(synth.make_subimages(rows, 128, dtype=np.float32)).to(dev)
     res = {}
-    for name, coll in (("collective_free", False), ("rccl_world1", True), ("collective_free_again", False)):
-        sf = ShardedFlow.for_flow(flow, K, rows, dev, collective=coll)
+    x_alts = [x, torch.roll(x, shifts=3, dims=0), torch.flip(x, dims=(0,))]
+    for name, coll, gs in (("collective_free", False, "side"), ("rccl_world1", True, "side"), ("rccl_world1_same_stream", True, "same"),
+                           ("collective_free_again", False, "side")):
+        sf = ShardedFlow.for_flow(flow, K, rows, dev, collective=coll, gather_stream=gs)
+        if coll:      # both forms of the gather against a blocking one, on inputs that change from step to step
+            assert sf.verify_against_blocking_gather(x_alts, steps=6), name
         for _ in range(300):
             sf.step(x)
         sf.wait()
@@ -150,7 +154,10 @@ def test_collective_step_costs_no_more_than_collective_free(rccl_world1):
         res[name] = (time.perf_counter() - t0) / 400 * 1e3
     print("ShardedFlow.step, 4096 rows U11L-128, ms/step:", {k: round(v, 4) for k, v in res.items()})
     base = min(res["collective_free"], res["collective_free_again"])
-    assert res["rccl_world1"] <= base + 0.025, res
+    # the kept (default) form is the side-stream gather: 13-16 us per step at world size 1 (profiles/r05_rccl_world1.txt) + 5 us;
+    # the same-stream form pays the copy that stands in for the gather serially and is bounded alike
+    assert res["rccl_world1"] <= base + 0.021, res
+    assert res["rccl_world1_same_stream"] <= base + 0.030, res
     flow.close()
 
 

@@ -19,11 +19,12 @@ flow = Flow.from_blob(blob, device=0, output_dtype=np.float32)
 dev = torch.device("cuda", 0)
 rows = 4096
 x = torch.from_numpy(synth.make_subimages(rows, 128, dtype=np.float32)).to(dev)
-VARIANTS = {"free": ("collective_free", False, None), "ordinary": ("rccl_world1, ordinary hand-off event", True, False),
-            "light": ("rccl_world1, device-scope hand-off event", True, True)}
-order = sys.argv[2].split(",") if len(sys.argv) > 2 else ["free", "ordinary", "light", "free"]
-for name, coll, light in [VARIANTS[k] for k in order]:
-    sf = ShardedFlow.for_flow(flow, 20, rows, dev, collective=coll, light_events=light)
+VARIANTS = {"free": ("collective_free", False, None, "side"), "ordinary": ("rccl_world1, ordinary hand-off event", True, False, "side"),
+            "light": ("rccl_world1, device-scope hand-off event", True, True, "side"),
+            "same": ("rccl_world1, gather on the kernels' own stream", True, None, "same")}
+order = sys.argv[2].split(",") if len(sys.argv) > 2 else ["free", "ordinary", "light", "same", "free"]
+for name, coll, light, gs in [VARIANTS[k] for k in order]:
+    sf = ShardedFlow.for_flow(flow, 20, rows, dev, collective=coll, light_events=light, gather_stream=gs)
     for _ in range(300):
         sf.step(x)
     sf.wait()
