@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhigsfa.so")
-SOURCES = ["hg_tree.cpp", "hg_capi.cpp", "hg_hostpack.cpp", "hg_generic.hip", "hg_fused.hip", "hg_fused_front.hip", "hg_fused_igsfa.hip", "hg_fused_prod.hip", "hg_fused_tail.hip", "hg_fused_merge.hip",
+SOURCES = ["hg_tree.cpp", "hg_capi.cpp", "hg_hostpack.cpp", "hg_generic.hip", "hg_fused.hip", "hg_fused_front.hip", "hg_fused_igsfa.hip", "hg_fused_prod.hip", "hg_fused_tail.hip",
            "hg_gauss.hip", "hg_extract.hip", "hg_cascade.hip", "hg_train.hip"]
 HEADERS = ["hg_common.hpp", os.path.join("..", "..", "include", "higsfa.h")]
 HOST_ONLY = {"hg_hostpack.cpp"}      # no HIP in them: built with g++ (function multiversioning, which the device pass rejects)

@@ -54,7 +54,6 @@ struct FusedOptions {
     int splitm_max_nodes = 4;     // experiments: HIGSFA_SPLITM_MAX
     int splitm_max_wgs = 512;     // HIGSFA_SPLITM_WGS: largest k_stage_splitm grid for layers of more than splitm_max_nodes nodes
     int shape_variant = 0;        // experiments: HIGSFA_SHAPES
-    bool no_merge = false;        // HIGSFA_NO_MERGE: every layer its own launch (no k_stage_mg)
     static FusedOptions from_env() {
         FusedOptions o;
         o.no_rem4 = getenv("HIGSFA_NO_REM4") != nullptr;
@@ -69,7 +68,6 @@ struct FusedOptions {
         o.no_fspec = getenv("HIGSFA_NO_FSPEC") != nullptr;
         o.no_direct = getenv("HIGSFA_NO_DIRECT") != nullptr;
         o.no_wgq = getenv("HIGSFA_NO_WGQ") != nullptr;
-        o.no_merge = getenv("HIGSFA_NO_MERGE") != nullptr || getenv("HIGSFA_WHATIF_OVERLAP") != nullptr;
         if (const char* e = getenv("HIGSFA_WQ_START")) o.wq_start = (uint32_t)strtoul(e, nullptr, 0);
         if (const char* e = getenv("HIGSFA_SPLITM_MAX")) o.splitm_max_nodes = atoi(e);
         if (const char* e = getenv("HIGSFA_SPLITM_WGS")) o.splitm_max_wgs = atoi(e);
@@ -1383,11 +1381,6 @@ public:
                 }
                 return R;
             };
-            if (whatif_forked_ && tail_begin_ >= 0 && (int)si == tail_start(n_tiles)) {      // timing experiment: join
-                HG_HIP(hipEventRecord(whatif_ev_[1], whatif_stream_));
-                HG_HIP(hipStreamWaitEvent(st, whatif_ev_[1], 0));
-                whatif_forked_ = false;
-            }
             if (tail_begin_ >= 0 && (int)si == tail_start(n_tiles)) {
                 // the top of the hierarchy as one launch that ends in the caller's rows (hg_fused_tail.hip)
                 TailParams TP = tail_params((int)si, cur, n_tiles, y, y_dtype, y_cols, ldy, n);
@@ -1634,84 +1627,61 @@ public:
                     if (ev) HG_HIP(hipEventRecord(ev[e++], st));
                     continue;
                 }
-                const KPlan K = plan_kstage(s, n_tiles);
-                // Consecutive layers that all run the 4 x 4 compile-time-expansion instantiation at full shape go out as ONE launch
-                // (k_stage_mg, hg_fused_merge.hip): look ahead while the next stage takes the same kernel
-                if (!opt_.no_merge && !ev_stamp_active() && mergeable(s, K, n_tiles)) {
-                    std::vector<KPlan> plans{K};
-                    size_t sj = si + 1;
-                    while (sj < stages_.size() && plans.size() < (size_t)kMaxMerge && !(tail_begin_ >= 0 && (int)sj == tail_start(n_tiles)) &&
-                           stages_[sj].kind == 0 && !takes_splitm(stages_[sj], n_tiles)) {
-                        KPlan Kn = plan_kstage(stages_[sj], n_tiles);
-                        if (!mergeable(stages_[sj], Kn, n_tiles) || Kn.tile_groups != K.tile_groups) break;
-                        plans.push_back(Kn);
-                        ++sj;
-                    }
-                    if (plans.size() >= 2) {
-                        const int m = (int)plans.size(), tg = K.tile_groups;
-                        MergeParams M{};
-                        M.n_stages = m;
-                        // per-layer, per-tile-group counters of finished producer waves: never reset while the shape of the call stays
-                        // the same (every launch adds n_chunks x 8 to every counter of a layer: `want` follows on the host)
-                        const int stride = 64 * std::max(16, (tg + 15) / 16 * 16);      // counters 64 words apart (kCtrPad, hg_fused_merge.hip)
-                        if (merge_done_.bytes < (size_t)kMaxMerge * stride * 4 || merge_tg_ != tg || merge_first_ != (int)si || merge_m_ != m) {
-                            merge_done_.alloc((size_t)kMaxMerge * stride * 4);
-                            HG_HIP(hipMemsetAsync(merge_done_.p, 0, merge_done_.bytes, st));      // behind every earlier launch of this stream
-                            for (auto& w : merge_want_) w = 0;
-                            merge_tg_ = tg;
-                            merge_first_ = (int)si;
-                            merge_m_ = m;
-                            merge_stride_ = stride;
-                        }
-                        M.done = (uint32_t*)merge_done_.p;
-                        M.done_stride = merge_stride_;
-                        M.err = device_error_word();
-                        size_t lds_max = 0;
-                        int64_t blocks_total = 0;
-                        for (int k = 0; k < m; ++k) {
-                            HostStage& hs = stages_[si + k];
-                            // outputs of the merged layers but the last go to buffers of their own: nothing is rewritten inside the launch
-                            if (k + 1 < m) merge_buf_[k].alloc((size_t)n_tiles * hs.nb_out * 1024);
-                            const f32x4* in_k = k == 0 ? cur : (const f32x4*)merge_buf_[k - 1].p;
-                            f32x4* out_k = k + 1 < m ? (f32x4*)merge_buf_[k].p : nxt;
-                            StageParams Q = base_params(hs, in_k, out_k);
-                            Q.nodes_per_group = plans[k].npg;
-                            Q.nodes_per_wg = plans[k].npg;
-                            Q.n_chunks = plans[k].n_groups;
-                            Q.tile_groups = plans[k].tile_groups;
-                            Q.tile_parts = plans[k].tile_parts;
-                            M.st[k] = Q;
-                            blocks_total += plans[k].blocks;
-                            M.blk_end[k] = (int32_t)blocks_total;
-                            merge_want_[k] += (uint32_t)plans[k].n_groups * 8u;
-                            M.want[k] = merge_want_[k];
-                            lds_max = std::max(lds_max, plans[k].lds_bytes);
-                        }
-                        if (blocks_total > 0x7fffffffll) fail(HG_ERR_ARG, "batch too large");
-                        set_lds_limit((StageFn)stage_merged_fn(4, 4), lds_max);
-                        launch_stage_merged(M, 4, 4, (unsigned)blocks_total, lds_max, st);
-                        std::swap(cur, nxt);
-                        if (ev)
-                            for (size_t k = si; k < sj; ++k) HG_HIP(hipEventRecord(ev[e++], st));   // the first event carries the launch's time
-                        si = sj - 1;
-                        continue;
+                // node groups sized so a group's weights are ~64 KiB of LDS (always >= 1 node)
+                const int npg = std::max(1, std::min(s.n_nodes, kWeightLdsKiB / std::max(1, s.node_blocks)));
+                const int n_groups = (s.n_nodes + npg - 1) / npg;
+                // waves x tiles per workgroup: the largest shape that still yields >= 512 workgroups
+                // waves x tiles per workgroup: the largest shape that still gives every CU a
+                // workgroup; never fewer than 4 waves to copy a node's weights unless the batch is tiny
+                static const int shapes0[][2] = {{8, 2}, {4, 2}, {4, 1}, {0, 0}};
+                static const int shapes1[][2] = {{8, 2}, {8, 1}, {4, 1}, {0, 0}};
+                static const int shapes2[][2] = {{8, 2}, {8, 1}, {4, 2}, {4, 1}};
+                const int (*shapes)[2] = opt_.shape_variant == 1 ? shapes1 : opt_.shape_variant == 3 ? shapes0 : shapes2;      // default: 8 x 1 before 4 x 2 (layer 7: 20.6 -> 19.0 us)
+                int nw = 4, T = 1;
+                for (int si2 = 0; si2 < 4; ++si2) {
+                    const int* sh = shapes[si2];
+                    if (!sh[0]) break;
+                    int64_t tg = (n_tiles + sh[0] * sh[1] - 1) / (sh[0] * sh[1]);
+                    if (sh[0] * sh[1] <= n_tiles && tg * n_groups >= 256) {
+                        nw = sh[0];
+                        T = sh[1];
+                        break;
                     }
                 }
-                const int npg = K.npg, n_groups = K.n_groups, nw = K.nw, tile_groups = K.tile_groups, tile_parts = K.tile_parts, kbf = K.kbf;
-#ifdef HIGSFA_DIAG
-                const int T = K.T;
-#endif
-                const int64_t blocks = K.blocks;
-                if (blocks > 0x7fffffffll) fail(HG_ERR_ARG, "batch too large");
-                const size_t lds_bytes = K.lds_bytes;
-                StageFn fn = K.fn;
+                while (nw * T > std::max(n_tiles, 1) && nw > 1) nw >>= 1;
+                const int tile_groups = (n_tiles + nw * T - 1) / (nw * T);
+                // persistent sweep: each workgroup copies its node group's weights once and walks
+                // tile groups part, part + tile_parts, ...; aim at ~3 workgroups per CU in total
+                // cost(P) = rounds of resident workgroups x (weight copy + tile iterations per workgroup)
+                const int64_t g8 = (int64_t)(n_groups + 7) / 8 * 8;
+                size_t lds_probe = (size_t)npg * s.node_blocks * 1024 + (size_t)npg * s.bias_floats * 4 + (size_t)npg * s.kb1 * 8;
+                const int kbf = (T == 2 && s.mt1 == s.mt2 && (s.mt1 == 2 || s.mt1 == 3) && !opt_.no_prefetch_all)
+                                    ? (s.kb1 == 4 ? 4 : (s.kb1 == 3 && s.rem4 ? 3 : 0)) : 0;
+                const bool fs = s.has_exp && s.nf == 2 && s.funcs[0].kind == E_IDENTITY && s.funcs[1].kind == E_ABS_POW && !opt_.no_fspec;
+                // slot-major packed input (plan_slot_major): the whole-visit-prefetch instantiation reads it at a fixed code position; any
+                // other shape of this call (one tile per wave: small batches) takes the generic remainder-tile loop, which tests per block
+                StageFn fn = s.pk_kbi >= 0 ? (kbf == 3 ? pick_stage(s.mt1, s.mt2, T, s.rem4, kbf, fs, s.pk_kbi) : nullptr) : pick_stage(s.mt1, s.mt2, T, s.rem4, kbf, fs);
+                if (!fn) fn = pick_stage(s.mt1, s.mt2, T, s.rem4, 0, false);
+                const double capacity = 256.0 * resident_blocks(fn, nw * 64, lds_probe);
+                int tile_parts = 1;
+                double best = 1e300;
+                for (int pp = 1; pp <= tile_groups; ++pp) {
+                    double rounds = std::ceil(g8 * pp / capacity);
+                    double cost = rounds * (0.35 + (double)((tile_groups + pp - 1) / pp));
+                    if (cost < best - 1e-9) {
+                        best = cost;
+                        tile_parts = pp;
+                    }
+                }
                 P.nodes_per_group = npg;
                 P.nodes_per_wg = npg;
                 P.n_chunks = n_groups;
                 P.pair_chunks = (s.pack_out && !s.pack_soa && npg == 2 && n_groups % 16 == 0 && !getenv("HIGSFA_NO_PAIR")) ? 1 : 0;
                 P.tile_groups = tile_groups;
                 P.tile_parts = tile_parts;
-                (void)kbf;
+                const int64_t blocks = (int64_t)((P.n_chunks + 7) / 8) * 8 * tile_parts;
+                if (blocks > 0x7fffffffll) fail(HG_ERR_ARG, "batch too large");
+                size_t lds_bytes = (size_t)npg * s.node_blocks * 1024 + (size_t)npg * s.bias_floats * 4 + (size_t)npg * s.kb1 * 8;
 #ifdef HIGSFA_DIAG
                 const bool stamp_kbf3 = s.mt1 == 3 && s.mt2 == 3 && T == 2 && s.rem4 && kbf == 3;
                 if (opt_.stamp_stage == (int)si && (stamp_kbf3 || (s.mt1 == s.mt2 && (s.mt1 == 4 || s.mt1 == 3) && T == 2 && !s.rem4 && kbf == 0))) {
@@ -1727,27 +1697,7 @@ public:
 #ifdef HIGSFA_DIAG
                 if (const char* e = getenv("HIGSFA_WHATIF")) P.whatif = atoi(e);
 #endif
-                {
-                    // TIMING EXPERIMENT, WRONG RESULTS (HIGSFA_WHATIF_OVERLAP=<first stage>, read per launch; round 5): k_stage launches from
-                    // that stage on alternate between the caller's stream and a second one WITHOUT waiting for one another, joined before
-                    // the top-of-hierarchy launch — what a merged launch with device-side dependencies could gain at most
-                    static const char* wo = getenv("HIGSFA_WHATIF_OVERLAP");
-                    hipStream_t ls = st;
-                    if (wo && (int)si >= atoi(wo)) {
-                        if (!whatif_stream_) {
-                            HG_HIP(hipStreamCreateWithFlags(&whatif_stream_, hipStreamNonBlocking));
-                            HG_HIP(hipEventCreateWithFlags(&whatif_ev_[0], hipEventDisableTiming));
-                            HG_HIP(hipEventCreateWithFlags(&whatif_ev_[1], hipEventDisableTiming));
-                        }
-                        if (!whatif_forked_) {
-                            HG_HIP(hipEventRecord(whatif_ev_[0], st));
-                            HG_HIP(hipStreamWaitEvent(whatif_stream_, whatif_ev_[0], 0));
-                            whatif_forked_ = true;
-                        }
-                        if (((int)si - atoi(wo)) & 1) ls = whatif_stream_;
-                    }
-                    hipLaunchKernelGGL(fn, (unsigned)blocks, nw * 64, lds_bytes, ls, P);
-                }
+                hipLaunchKernelGGL(fn, (unsigned)blocks, nw * 64, lds_bytes, st, P);
                 if (P.stamps) {
                     HG_HIP(hipStreamSynchronize(st));
                     std::vector<unsigned long long> h((size_t)stamp_blocks_ * 8 * 8);
@@ -1794,9 +1744,6 @@ public:
         wq_front_.ctr.free();
         wq_direct_.ctr.free();
         wq_direct_wg_.ctr.free();
-        for (auto& b : merge_buf_) b.free();
-        merge_done_.free();
-        merge_tg_ = -1;
         if (err_host_) (void)hipHostFree(err_host_);
         err_host_ = nullptr;
         err_dev_ = nullptr;
@@ -1810,76 +1757,6 @@ public:
     }
 
 private:
-    // does stage s of a call with n_tiles batch tiles run on k_stage_splitm? (the condition of run_range, shared with the merge look-ahead)
-    bool takes_splitm(const HostStage& s, int n_tiles) const {
-        const int T_sm = n_tiles >= 2 * 256 / std::max(1, s.n_nodes) ? 2 : 1;
-        const int64_t wgs_sm = (int64_t)((n_tiles + T_sm - 1) / T_sm) * s.n_nodes;
-        return s.kind == 0 && (!s.rem4 || s.mt1 == s.mt2) && (s.rem4 || !s.pack_out) && s.mt1 * s.nf <= 8 &&
-               (s.n_nodes <= opt_.splitm_max_nodes ? (int64_t)s.n_nodes * n_tiles <= 8192 : wgs_sm <= opt_.splitm_max_wgs);
-    }
-
-    // launch shape of a k_stage launch of stage s (what run_range computed inline until round 5)
-    struct KPlan {
-        int npg = 1, n_groups = 1, nw = 4, T = 1, tile_groups = 1, tile_parts = 1, kbf = 0;
-        bool fs = false;
-        int64_t blocks = 0;
-        size_t lds_bytes = 0;
-        StageFn fn = nullptr;
-    };
-    KPlan plan_kstage(const HostStage& s, int n_tiles) {
-        KPlan K;
-        // node groups sized so a group's weights are ~64 KiB of LDS (always >= 1 node)
-        K.npg = std::max(1, std::min(s.n_nodes, kWeightLdsKiB / std::max(1, s.node_blocks)));
-        K.n_groups = (s.n_nodes + K.npg - 1) / K.npg;
-        // waves x tiles per workgroup: the largest shape that still gives every CU a
-        // workgroup; never fewer than 4 waves to copy a node's weights unless the batch is tiny
-        static const int shapes0[][2] = {{8, 2}, {4, 2}, {4, 1}, {0, 0}};
-        static const int shapes1[][2] = {{8, 2}, {8, 1}, {4, 1}, {0, 0}};
-        static const int shapes2[][2] = {{8, 2}, {8, 1}, {4, 2}, {4, 1}};
-        const int (*shapes)[2] = opt_.shape_variant == 1 ? shapes1 : opt_.shape_variant == 3 ? shapes0 : shapes2;      // default: 8 x 1 before 4 x 2 (layer 7: 20.6 -> 19.0 us)
-        for (int si2 = 0; si2 < 4; ++si2) {
-            const int* sh = shapes[si2];
-            if (!sh[0]) break;
-            int64_t tg = (n_tiles + sh[0] * sh[1] - 1) / (sh[0] * sh[1]);
-            if (sh[0] * sh[1] <= n_tiles && tg * K.n_groups >= 256) {
-                K.nw = sh[0];
-                K.T = sh[1];
-                break;
-            }
-        }
-        while (K.nw * K.T > std::max(n_tiles, 1) && K.nw > 1) K.nw >>= 1;
-        K.tile_groups = (n_tiles + K.nw * K.T - 1) / (K.nw * K.T);
-        // persistent sweep: each workgroup copies its node group's weights once and walks
-        // tile groups part, part + tile_parts, ...; aim at ~3 workgroups per CU in total
-        // cost(P) = rounds of resident workgroups x (weight copy + tile iterations per workgroup)
-        const int64_t g8 = (int64_t)(K.n_groups + 7) / 8 * 8;
-        K.lds_bytes = (size_t)K.npg * s.node_blocks * 1024 + (size_t)K.npg * s.bias_floats * 4 + (size_t)K.npg * s.kb1 * 8;
-        K.kbf = (K.T == 2 && s.mt1 == s.mt2 && (s.mt1 == 2 || s.mt1 == 3) && !opt_.no_prefetch_all) ? (s.kb1 == 4 ? 4 : (s.kb1 == 3 && s.rem4 ? 3 : 0)) : 0;
-        K.fs = s.has_exp && s.nf == 2 && s.funcs[0].kind == E_IDENTITY && s.funcs[1].kind == E_ABS_POW && !opt_.no_fspec;
-        // slot-major packed input (plan_slot_major): the whole-visit-prefetch instantiation reads it at a fixed code position; any
-        // other shape of this call (one tile per wave: small batches) takes the generic remainder-tile loop, which tests per block
-        K.fn = s.pk_kbi >= 0 ? (K.kbf == 3 ? pick_stage(s.mt1, s.mt2, K.T, s.rem4, K.kbf, K.fs, s.pk_kbi) : nullptr) : pick_stage(s.mt1, s.mt2, K.T, s.rem4, K.kbf, K.fs);
-        if (!K.fn) K.fn = pick_stage(s.mt1, s.mt2, K.T, s.rem4, 0, false);
-        const double capacity = 256.0 * resident_blocks(K.fn, K.nw * 64, K.lds_bytes);
-        double best = 1e300;
-        for (int pp = 1; pp <= K.tile_groups; ++pp) {
-            double rounds = std::ceil(g8 * pp / capacity);
-            double cost = rounds * (0.35 + (double)((K.tile_groups + pp - 1) / pp));
-            if (cost < best - 1e-9) {
-                best = cost;
-                K.tile_parts = pp;
-            }
-        }
-        K.blocks = (int64_t)((K.n_groups + 7) / 8) * 8 * K.tile_parts;
-        return K;
-    }
-    // a stage whose k_stage launch k_stage_mg can take over: the compile-time-expansion instantiation of 4 x 4 tiles at two tiles per
-    // wave and eight waves, no remainder tiles, no packed blocks on either side, byte offsets that fit 32 bits
-    bool mergeable(const HostStage& s, const KPlan& K, int n_tiles) const {
-        return s.kind == 0 && !s.from_x && s.has_exp && s.mt1 == 4 && s.mt2 == 4 && K.T == 2 && K.nw == 8 && K.kbf == 0 && K.fs && !s.rem4 && !s.pack_out &&
-               s.pk_kbi < 0 && s.pack_in == 0x7fffffff && (int64_t)n_tiles * std::max(s.nb_in, s.nb_out) * 1024 < 0x7fffffffll;
-    }
-
     // resident workgroups per CU for (kernel, block size, LDS) — cached occupancy query
     int resident_blocks(StageFn fn, int threads, size_t lds) {
         set_lds_limit(fn, lds);
@@ -2708,14 +2585,6 @@ private:
     int tail_begin_ = -1;         // first stage of the top-of-hierarchy launch (k_tail); -1: none
     int tail_act_blocks_ = 0, tail_e_blocks_ = 0;
     WorkQueue wq_front_, wq_direct_, wq_direct_wg_;
-    // k_stage_mg (hg_fused_merge.hip): outputs of merged layers, the tile-group counters and the values they reach per launch
-    DevBuf merge_buf_[kMaxMerge], merge_done_;
-    uint32_t merge_want_[kMaxMerge] = {};
-    int merge_tg_ = -1, merge_first_ = -1, merge_m_ = 0, merge_stride_ = 0;
-    bool ev_stamp_active() const { return opt_.stamp_stage >= 0; }
-    hipStream_t whatif_stream_ = nullptr;      // HIGSFA_WHATIF_OVERLAP (timing experiment)
-    hipEvent_t whatif_ev_[2] = {};
-    bool whatif_forked_ = false;
     int32_t* err_host_ = nullptr;
     int32_t* err_dev_ = nullptr;
     int stamp_blocks_ = 0;

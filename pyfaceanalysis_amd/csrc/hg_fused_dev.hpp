@@ -295,26 +295,9 @@ __device__ __forceinline__ float* packed_slot_ptr(const StageParams& P, int tile
 // wA2 / b2 point at this node's A2 fragments (+lane) and bias-2 fragment; address space (LDS or
 // global) is resolved after inlining.
 // FS: the expansion is (identity, |x|^p) and known at compile time (as in the front kernel): no function loop, no kind branches.
-// How node_tail stores an output block: through the stage's out pointer, or (k_stage_mg: consumers of the SAME launch on other
-// XCDs read it) as a write-through buffer store — aux = 16 is the sc1 bit (cdna_hip_programming.md Guideline 16) — through a
-// resource over the stage's output buffer.
-struct PlainStore {
-    __device__ __forceinline__ void operator()(const StageParams& P, uint32_t blk, int lane, f32x4 v) const { P.out[(size_t)blk * 64 + lane] = v; }
-};
-struct Sc1Store {
-    __amdgpu_buffer_rsrc_t r;
-    __device__ __forceinline__ void operator()(const StageParams&, uint32_t blk, int lane, f32x4 v) const {
-        typedef uint32_t u32x4_s __attribute__((ext_vector_type(4)));
-#ifndef HG_MG_STORE_AUX
-#define HG_MG_STORE_AUX 16
-#endif
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_s, v), r, (uint32_t)lane * 16u, blk * 1024u, HG_MG_STORE_AUX);
-    }
-};
-
-template <int MT1, int MT2, int T, bool REM = false, bool FS = false, typename WP, typename BP, typename ST = PlainStore>
+template <int MT1, int MT2, int T, bool REM = false, bool FS = false, typename WP, typename BP>
 __device__ __forceinline__ void node_tail(const StageParams& P, WP wA2, BP b2, int node, f32x4 (&z)[MT1][T],
-                                          const int (&tile)[T], int lane, ST store = ST()) {
+                                          const int (&tile)[T], int lane) {
     const int g = lane >> 4;
     const int out_blk = node * P.mto;
 #ifdef HIGSFA_DIAG
@@ -412,7 +395,7 @@ __device__ __forceinline__ void node_tail(const StageParams& P, WP wA2, BP b2, i
     for (int mt = 0; mt < MT2; ++mt)
 #pragma unroll
         for (int t = 0; t < T; ++t)
-            if (tile[t] < P.n_tiles && !no_store) store(P, (uint32_t)tile[t] * (uint32_t)P.nb_out + (uint32_t)(out_blk + mt), lane, y[mt][t]);
+            if (tile[t] < P.n_tiles && !no_store) P.out[((size_t)tile[t] * P.nb_out + out_blk + mt) * 64 + lane] = y[mt][t];
 }
 
 
@@ -443,26 +426,6 @@ size_t tail_lds_bytes(const TailParams& P, int T);
 int tail_waves(const TailParams& P);
 void launch_tail(const TailParams& P, int T, hipStream_t st);
 
-
-// k_stage_mg (hg_fused_merge.hip, round 5): SEVERAL consecutive layers in one launch.  Blocks [blk_end[s-1], blk_end[s]) run layer s
-// exactly as its own k_stage launch would; a layer's workgroups follow the previous layer's in block order, so they are dispatched as
-// those drain and their start-up (the copy of a node's weights into LDS, the first loads) and the previous layer's low-occupancy
-// tail overlap — what two independent batches in flight gain, inside one batch.  A wave may read tile group g of layer s - 1's output
-// once every wave of every workgroup of layer s - 1 that owns group g has stored its tiles (write-through stores, then one
-// device-scope atomic add on done[s - 1][g]); `want[s]` is the value that counter has when layer s has finished a group in THIS
-// launch (counters are never reset; 32-bit wrap-around is harmless).  Outputs of merged layers go to buffers of their own (no
-// buffer is rewritten inside a launch).  Polls are bounded: one that runs out writes *err and the launch still drains.
-constexpr int kMaxMerge = 6;
-struct MergeParams {
-    StageParams st[kMaxMerge];
-    int32_t n_stages, done_stride;
-    int32_t blk_end[kMaxMerge];
-    uint32_t want[kMaxMerge];
-    uint32_t* done;           // [kMaxMerge][done_stride]
-    int32_t* err;
-};
-void launch_stage_merged(const MergeParams& M, int mt1, int mt2, unsigned blocks, size_t lds_bytes, hipStream_t st);      // hg_fused_merge.hip
-const void* stage_merged_fn(int mt1, int mt2);
 
 typedef void (*StageFn)(StageParams);
 typedef void (*StageFn2)(StageParams, StageParams);

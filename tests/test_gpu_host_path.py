@@ -166,51 +166,6 @@ def test_batch_size_dependence_is_bounded(native_lib, nets, monkeypatch):
     generic.close()
 
 
-def test_merged_layer_launch_equals_per_layer_launches(native_lib, nets, monkeypatch):
-    """Round 5: the 4 x 4-tile middle layers of U11L-128 (layers 3-6 at N = 4096) go out as ONE launch whose workgroups wait, per
-    16-tile group, on counters in device memory for the layer below (k_stage_mg, hg_fused_merge.hip) — the same products in the same
-    order as one k_stage launch per layer (HIGSFA_NO_MERGE=1, read when a flow is loaded): bit-identical features, at full and
-    ragged batch sizes (tile counts that leave waves without tiles, a last tile with a few rows), when the shape of the call
-    changes between calls (the counters are re-based), over many back-to-back calls (counters only ever grow), and on U11L-64."""
-    import torch
-    x = synth.make_subimages(4101, 128, dtype=np.uint8)
-    nodes = nets("U11L-128")
-    monkeypatch.setenv("HIGSFA_NO_MERGE", "1")
-    plain = Flow(nodes, output_dtype=np.float32)
-    monkeypatch.delenv("HIGSFA_NO_MERGE")
-    merged = Flow(nodes, output_dtype=np.float32)
-    ref = plain.execute(x, n_cols=20)
-    x2 = np.ascontiguousarray(x[::-1])          # other rows at every position: a stale activation block of the call before cannot pass
-    ref2 = plain.execute(x2, n_cols=20)
-    for i, n in enumerate((4096, 4101, 4097, 1738, 4096, 2049, 3000, 4096, 728, 4096, 4096)):
-        xi, ri = (x, ref) if i % 2 == 0 else (x2, ref2)
-        assert np.array_equal(merged.execute(xi[:n], n_cols=20), ri[:n]), n
-    full = plain.execute(x[:2500])
-    assert np.array_equal(merged.execute(x[:2500]), full)
-    # many calls back to back on one stream without a host synchronisation in between, alternating inputs: every launch's counters
-    # continue where the last launch left them
-    dev = torch.device("cuda", 0)
-    xa, xb = torch.from_numpy(x[:4096]).to(dev), torch.from_numpy(np.ascontiguousarray(x[5:4101])).to(dev)
-    ya, yb = (torch.empty((4096, 20), dtype=torch.float32, device=dev) for _ in range(2))
-    st = torch.cuda.current_stream(dev).cuda_stream
-    for i in range(300):
-        src, dst = (xa, ya) if i % 2 == 0 else (xb, yb)
-        merged.execute_device(src.data_ptr(), np.uint8, 4096, 16384, dst.data_ptr(), np.float32, 20, 20, stream=st)
-    torch.cuda.synchronize()
-    assert np.array_equal(ya.cpu().numpy(), ref[:4096]) and np.array_equal(yb.cpu().numpy(), ref[5:4101])
-    plain.close()
-    merged.close()
-    nodes64 = nets("U11L-64")
-    x64 = synth.make_subimages(4096, 64, dtype=np.uint8)
-    monkeypatch.setenv("HIGSFA_NO_MERGE", "1")
-    plain = Flow(nodes64, output_dtype=np.float32)
-    monkeypatch.delenv("HIGSFA_NO_MERGE")
-    merged = Flow(nodes64, output_dtype=np.float32)
-    assert np.array_equal(merged.execute(x64), plain.execute(x64))
-    plain.close()
-    merged.close()
-
-
 def test_top_of_hierarchy_launch(native_lib, nets, monkeypatch):
     """The last layers of U11L-128 (4, 2, 1 nodes) run as ONE launch that keeps the activations in LDS and writes the
     caller's rows itself (k_tail, hg_fused_tail.hip; HIGSFA_TAIL = how many layers it may fuse, 0 = per-layer launches +
