@@ -33,7 +33,7 @@ PRESET = "U11L-128"
 PEAK_MFMA_F32_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0
 PEAK_MFMA_F64_TFLOPS = 78.6      # MI355X data sheet: FP64 matrix = FP64 vector = half the FP32 rate above (the guide lists no fp64 row)
-TRAFFIC_PROFILE = "r04_traffic.json"   # committed PMC summary the roofline's `traffic` is read from
+TRAFFIC_PROFILE = "r05_traffic.json"   # committed PMC summary the roofline's `traffic` is read from
 
 
 def cpu_baseline(nodes, n=256, reps=6):

@@ -979,6 +979,8 @@ struct HostStage {
     std::vector<int32_t> gcol;
     DevBuf d_gcol;
     int64_t mfma_per_tile = 0;
+    int64_t mfma16_tile = 0, mfma4_tile = 0;      // instructions issued per batch tile, all nodes of the layer
+    int64_t ks1_tile = 0, ks2_tile = 0;      // k-steps of the first / second affine summed over the layer's nodes (per batch tile): issue accounting
     std::string name;
     DevBuf d_afrag, d_bias, d_kb1tab, d_chunks, d_runs, d_piece, d_koff, d_kmean, d_kcol;
 };
@@ -1117,6 +1119,7 @@ public:
                         hs.kb1tab[((size_t)ni * hs.kb1 + kb) * 2 + 1] = K.nk[kb] | (r0 << 8);
                     }
                     hs.mfma_per_tile += (int64_t)(K.nk[kb] - r0) * hs.mt1;
+                    hs.ks1_tile += K.nk[kb] - r0;
                     for (int mt = 0; mt < hs.mt1; ++mt) {
                         float* blk = wnode + ((size_t)kb * hs.mt1 + mt) * 256;
                         for (int lane = 0; lane < 64; ++lane) {
@@ -1159,6 +1162,7 @@ public:
                         for (int fi = 0; fi < hs.nf; ++fi) {
                             const int used = nd.funcs[fi].used(p);
                             hs.mfma_per_tile += (int64_t)hs.nk2[mt1][fi] * hs.mt2;
+                            hs.ks2_tile += hs.nk2[mt1][fi];
                             for (int mt2 = 0; mt2 < hs.mt2; ++mt2) {
                                 float* blk = w2 + ((size_t)(mt1 * hs.nf + fi) * hs.mt2 + mt2) * 256;
                                 for (int lane = 0; lane < 64; ++lane) {
@@ -1255,11 +1259,21 @@ public:
             prev_q.swap(cur_q);
             prev_nb = hs.nb_out;
             max_nb_ = std::max(max_nb_, hs.nb_out);
-            padded_flops_ += hs.mfma_per_tile * 2048 / 16;
+            {
+                // What the kernels ISSUE per 16-row tile: an affine's tile of <= 4 real rows runs on v_mfma_f32_4x4x1 (512 FLOP, 8 cycles)
+                // where the stage has remainder tiles — decided above for k_stage, at run time with the same rule for layer 1 inside the
+                // front kernel — every other tile on v_mfma_f32_16x16x4 (2048 FLOP, 32 cycles).  Round 4 counted every tile as 16 x 16.
+                const bool front_rem = si == 1 && hs.has_exp && hs.mt1 == 2 && hs.mt2 == 2 && hs.p_max <= 20 && hs.s_max <= 20 && hs.nk2[1][0] <= 1 &&
+                                       hs.nk2[1][1] <= 1 && !opt_.no_rem4;
+                const int rem = (hs.rem4 || front_rem) ? 1 : 0;
+                hs.mfma16_tile = hs.ks1_tile * (hs.mt1 - rem) + (hs.has_exp ? hs.ks2_tile * (hs.mt2 - rem) : 0);
+                hs.mfma4_tile = rem ? hs.ks1_tile + hs.ks2_tile : 0;
+            }
+            padded_flops_ += (hs.mfma16_tile * 2048 + hs.mfma4_tile * 512) / 16;
             std::ostringstream os;
             os << "fused stage " << si << (hs.rem4 ? (hs.pack_out ? " (4x4 remainder tiles, packed four to a block)" : " (4x4 remainder tiles)") : "") << ": " << hs.n_nodes << " nodes, K-blocks " << hs.kb1 << ", tiles " << hs.mt1 << "x" << hs.mt2
-               << ", " << hs.mfma_per_tile << " MFMA/tile, " << hs.afrag.size() * 4 / 1024 << " KiB weights, out " << hs.nb_out
-               << " blocks/tile";
+               << ", " << hs.mfma_per_tile << " MFMA/tile (issued: " << hs.mfma16_tile << " x 16x16x4 + " << hs.mfma4_tile << " x 4x4x1), " << hs.afrag.size() * 4 / 1024
+               << " KiB weights, out " << hs.nb_out << " blocks/tile";
             hs.name = os.str();
         }
         plan_slot_major();

@@ -92,6 +92,7 @@ lines = ["# rocprofv3 summary %s — `bench.py --steps 200 --warmup 30` (4096 x 
          "| # | kernel | grid | calls | avg us | HBM read MB | HBM write MB | GB/s | GHz | MFMA busy | busy (GRBM base) | VALU : TRANS : MFMA instr (M) | co-exec | issue bound | bound x clock | achieved | LDS bank-conflict share |",
          "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
 traffic = {}
+counters_out = {}      # per launch position: the raw counters the issue table is built from (tools/issue_table.py)
 for (pos, k, grid), v in dur.items():
     avg = sum(v) / len(v)
     fk = fetch.get((pos, k, grid), {}).get("FETCH_SIZE")
@@ -131,9 +132,13 @@ for (pos, k, grid), v in dur.items():
         pct(busy), pct(busy_grbm), mixs or "-", pct(coex), pct(ib), pct(ibc), pct(ach), pct(conf)))
     if rd is not None and wr is not None:
         traffic["%d|%s" % (pos, k)] = {"hbm_read_bytes": rd, "hbm_write_bytes": wr, "avg_us": avg}
+    counters_out["%d|%s" % (pos, k)] = {"avg_us": avg, "grid": grid, "layers": layer_of.get(pos, []), "ghz": ghz,
+                                        **{n: m.get(n) for n in ("SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_INSTS_VALU_TRANS_F32")},
+                                        **{n: s.get(n) for n in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_BUSY_CYCLES", "SQ_WAVES")}}
 tot = sum(sum(v) / len(v) for v in dur.values())
 top = sum(sum(v) / len(v) for (pos, k, grid), v in dur.items() if pos >= 5)
 lines += ["", "Total kernel time per step: %.1f us; layers 6-10 and the row-major output (positions >= 5): %.1f us" % (tot, top)]
 open(os.path.join(P, tag + "_summary.md"), "w").write("\n".join(lines) + "\n")
 json.dump(traffic, open(os.path.join(P, tag + "_traffic.json"), "w"), indent=1)
+json.dump(counters_out, open(os.path.join(P, tag + "_counters.json"), "w"), indent=1)
 print("\n".join(lines))
