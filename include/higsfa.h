@@ -206,6 +206,13 @@ void hg_patcher_free(hg_patcher* p);
 int hg_patcher_extract_device(hg_patcher* p, const void* frame_dev, int frame_dtype, int frame_h, int frame_w,
                               int64_t ld, const double* boxes_dev, int64_t n, int out_w, int out_h,
                               void* out_dev, int out_dtype, int64_t ldo, void* stream);
+/* The same for boxes the caller declares UNCHANGED between calls (key != 0; e.g. the prescale's whole-frame box, the first-stage
+ * grid of a frame size, which depend on the frame's size only — face_analysis.py:630-669): the index tables are built on the first
+ * call with a key (and whenever n or a size differs from what the key was built for) and reused afterwards.  Unrotated windows.
+ * key = 0: hg_patcher_extract_device. */
+int hg_patcher_extract_keyed_device(hg_patcher* p, uint64_t key, const void* frame_dev, int frame_dtype, int frame_h, int frame_w,
+                                    int64_t ld, const double* boxes_dev, int64_t n, int out_w, int out_h, void* out_dev,
+                                    int out_dtype, int64_t ldo, void* stream);
 int hg_patcher_extract(hg_patcher* p, const void* frame, int frame_dtype, int frame_h, int frame_w, int64_t ld,
                        const double* boxes, int64_t n, int out_w, int out_h, void* out, int out_dtype,
                        int64_t ldo);

@@ -101,6 +101,7 @@ def lib():
         "hg_patcher_create": (C.c_int, [i32, C.POINTER(vp)]),
         "hg_patcher_free": (None, [vp]),
         "hg_patcher_extract_device": (C.c_int, [vp, vp, i32, i32, i32, i64, vp, i64, i32, i32, vp, i32, i64, vp]),
+        "hg_patcher_extract_keyed_device": (C.c_int, [vp, C.c_uint64, vp, i32, i32, i32, i64, vp, i64, i32, i32, vp, i32, i64, vp]),
         "hg_patcher_extract": (C.c_int, [vp, vp, i32, i32, i32, i64, vp, i64, i32, i32, vp, i32, i64]),
         "hg_patcher_extract_rotate_device": (C.c_int, [vp, vp, i32, i32, i32, i64, vp, vp, i64, i32, i32, vp, i32, i64, vp]),
         "hg_patcher_extract_rotate": (C.c_int, [vp, vp, i32, i32, i32, i64, vp, vp, i64, i32, i32, vp, i32, i64]),
@@ -131,7 +132,7 @@ EXPORTED_SYMBOLS = (
     "hg_flow_execute_device", "hg_event_create", "hg_event_create_on", "hg_event_destroy", "hg_event_record", "hg_stream_wait_event", "hg_event_query", "hg_flow_host_transport", "hg_host_pack_probe", "hg_host_store_probe", "hg_host_dma_probe", "hg_flow_set_profiling", "hg_flow_stage_times", "hg_flow_stage_name",
     "hg_flow_reset_profile", "hg_gauss_create", "hg_gauss_free", "hg_gauss_regression_device",
     "hg_gauss_regression", "hg_patcher_create", "hg_patcher_free", "hg_patcher_extract_device",
-    "hg_patcher_extract", "hg_patcher_extract_rotate_device", "hg_patcher_extract_rotate", "hg_cascade_update_device",
+    "hg_patcher_extract_keyed_device", "hg_patcher_extract", "hg_patcher_extract_rotate_device", "hg_patcher_extract_rotate", "hg_cascade_update_device",
     "hg_cascade_compact_device", "hg_gather_rows_device", "hg_cascade_create", "hg_cascade_free", "hg_cascade_detect_device",
     "hg_cascade_detect_levels_device", "hg_cascade_detect_frame_device", "hg_cascade_grid_device", "hg_gauss_regression_multi_device",
     "hg_sfa_train_layer", "hg_pca_train_layer", "hg_train_apply_device",

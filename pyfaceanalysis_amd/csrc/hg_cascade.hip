@@ -647,6 +647,12 @@ LevelTable make_level_table(const hg_cascade_level* levels, int n_levels) {
 }
 
 // The stage loop.  `T`: the windows come from the grid's closed form (k_cascade_init_grid), else from boxes_host / level_host.
+// FNV-1a over a plain struct: the key under which the patcher keeps index tables of boxes that depend on sizes only
+uint64_t key_of(const void* p, size_t n, uint64_t h = 1469598103934665603ull) {
+    for (size_t i = 0; i < n; ++i) h = (h ^ ((const unsigned char*)p)[i]) * 1099511628211ull;
+    return h ? h : 1;
+}
+
 void detect_impl(hg_cascade* c, const void* frame_dev, int frame_h, int frame_w, int64_t ld, const double* boxes_host, const double* level_host,
                  const LevelTable* T, int64_t n0, double* out_coords, double* out_angles, int32_t* out_orig_index, double* out_confidence,
                  int64_t out_cap, int64_t* n_out, int32_t* stage_counts, int64_t* rows_executed, void* stream) {
@@ -724,10 +730,13 @@ void detect_impl(hg_cascade* c, const void* frame_dev, int frame_h, int frame_w,
         }
         const bool skip_extract = (k > 0 && c->stages[k - 1].type == HG_STAGE_DISC) || !S.flow;      // FaceDetectUpdated.py:674-681
         if (!skip_extract) {
-            // (the first stage's angles are all zero: the plain EXTENT kernel — a window with delta_ang == 0 is cut from the frame itself)
-            if (hg_patcher_extract_rotate_device(c->patcher, frame_dev, HG_U8, frame_h, frame_w, ld, (const double*)c->coords[cur].p,
-                                                 k == 0 ? nullptr : (const double*)c->neg.p, n_bound, c->w, c->h, c->subs[sb].p, HG_U8, (int64_t)row, st) != HG_OK)
-                hg::fail(HG_ERR_DEVICE, "%s", hg_last_error());
+            // (the first stage's angles are all zero: the plain EXTENT kernel — a window with delta_ang == 0 is cut from the frame itself —
+            // and where the windows come from the level table they are a function of that table alone: their index tables are kept)
+            const int rc = k == 0 ? hg_patcher_extract_keyed_device(c->patcher, T ? key_of(T, sizeof *T) : 0, frame_dev, HG_U8, frame_h, frame_w, ld,
+                                                                    (const double*)c->coords[cur].p, n_bound, c->w, c->h, c->subs[sb].p, HG_U8, (int64_t)row, st)
+                                  : hg_patcher_extract_rotate_device(c->patcher, frame_dev, HG_U8, frame_h, frame_w, ld, (const double*)c->coords[cur].p,
+                                                                     (const double*)c->neg.p, n_bound, c->w, c->h, c->subs[sb].p, HG_U8, (int64_t)row, st);
+            if (rc != HG_OK) hg::fail(HG_ERR_DEVICE, "%s", hg_last_error());
         }
         if (S.flow) {
             if (hg_flow_execute_device(S.flow, c->subs[sb].p, HG_U8, n_bound, (int64_t)row, c->sl[cur].p, HG_F32, c->k, c->k, st) != HG_OK)
@@ -866,8 +875,10 @@ int hg_cascade_detect_frame_device(hg_cascade* c, const void* frame_dev, int fra
                 c->pre_src_h = frame_h;
             }
             c->pre_frame.alloc((size_t)prescale_w * prescale_h);
-            if (hg_patcher_extract_device(c->patcher, frame_dev, HG_U8, frame_h, frame_w, ld, (const double*)c->pre_box.p, 1, prescale_w, prescale_h,
-                                          c->pre_frame.p, HG_U8, (int64_t)prescale_w * prescale_h, stream) != HG_OK)
+            const int32_t pre_shape[4] = {frame_w, frame_h, prescale_w, prescale_h};      // the whole-frame box depends on these alone
+            if (hg_patcher_extract_keyed_device(c->patcher, key_of(pre_shape, sizeof pre_shape, 0x9e3779b97f4a7c15ull), frame_dev, HG_U8, frame_h, frame_w, ld,
+                                                (const double*)c->pre_box.p, 1, prescale_w, prescale_h, c->pre_frame.p, HG_U8,
+                                                (int64_t)prescale_w * prescale_h, stream) != HG_OK)
                 hg::fail(HG_ERR_DEVICE, "%s", hg_last_error());
             fr = c->pre_frame.p;
             fh = prescale_h;

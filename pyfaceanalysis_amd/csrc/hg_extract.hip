@@ -27,6 +27,16 @@
 struct hg_patcher {
     int device = -1;
     hg::DevBuf tabs, boxes, frame, out, rot, angles;
+    // hg_patcher_extract_keyed_device: index tables kept per key (boxes the CALLER declares unchanged: the prescale's whole-frame box, the
+    // first-stage grid of a frame size) — the table kernel then runs once, not once per frame
+    struct Keyed {
+        uint64_t key = 0;
+        int64_t n = 0;
+        int out_w = 0, out_h = 0, frame_w = 0, frame_h = 0;
+        hg::DevBuf tabs;
+    };
+    Keyed keyed[4];
+    int keyed_next = 0;
 };
 
 namespace hg { void set_last_error(const std::string& s); }
@@ -375,6 +385,34 @@ int hg_patcher_extract_rotate_device(hg_patcher* p, const void* frame_dev, int f
         } else {
             launch_gather<float>(frame_dev, ld, (const int32_t*)p->tabs.p, n, out_w, out_h, out_dev, out_dtype, ldo, st);
         }
+        HG_HIP(hipGetLastError());
+    });
+}
+
+int hg_patcher_extract_keyed_device(hg_patcher* p, uint64_t key, const void* frame_dev, int frame_dtype, int frame_h, int frame_w, int64_t ld,
+                                    const double* boxes_dev, int64_t n, int out_w, int out_h, void* out_dev, int out_dtype, int64_t ldo, void* stream) {
+    if (key == 0) return hg_patcher_extract_rotate_device(p, frame_dev, frame_dtype, frame_h, frame_w, ld, boxes_dev, nullptr, n, out_w, out_h, out_dev, out_dtype, ldo, stream);
+    return guarded([&] {
+        check_args(p, frame_dev, frame_dtype, frame_h, frame_w, ld, boxes_dev, n, out_w, out_h, out_dev, out_dtype, ldo);
+        if (n == 0) return;
+        HG_HIP(hipSetDevice(p->device));
+        hipStream_t st = (hipStream_t)stream;
+        const int64_t n_ent = n * (out_w + out_h);
+        if ((n_ent + 255) / 256 > 0x7fffffffll) hg::fail(HG_ERR_ARG, "too many boxes");
+        hg_patcher::Keyed* K = nullptr;
+        for (auto& k : p->keyed)
+            if (k.key == key && k.n == n && k.out_w == out_w && k.out_h == out_h && k.frame_w == frame_w && k.frame_h == frame_h) K = &k;
+        if (!K) {      // first use of this key (or its shape changed): build the tables, in stream order, into a buffer of their own
+            K = &p->keyed[p->keyed_next];
+            p->keyed_next = (p->keyed_next + 1) % 4;
+            if (K->tabs.p && (size_t)n_ent * 4 > K->tabs.bytes) HG_HIP(hipStreamSynchronize(st));      // a launch in flight may still read the old buffer
+            K->tabs.alloc((size_t)n_ent * 4);
+            K->key = key; K->n = n; K->out_w = out_w; K->out_h = out_h; K->frame_w = frame_w; K->frame_h = frame_h;
+            hipLaunchKernelGGL(k_extent_tables, (unsigned)((n_ent + 255) / 256), 256, 0, st, boxes_dev, n, out_w, out_h, frame_w, frame_h, (int32_t*)K->tabs.p,
+                               (const double*)nullptr, (RotCoef*)nullptr);
+        }
+        if (frame_dtype == HG_U8) launch_gather<uint8_t>(frame_dev, ld, (const int32_t*)K->tabs.p, n, out_w, out_h, out_dev, out_dtype, ldo, st);
+        else launch_gather<float>(frame_dev, ld, (const int32_t*)K->tabs.p, n, out_w, out_h, out_dev, out_dtype, ldo, st);
         HG_HIP(hipGetLastError());
     });
 }

@@ -469,7 +469,12 @@ __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
         {   // cooperative copy of the group's weights, 8 x 16 B in flight per thread (an L2 round trip is
             // ~2k cycles here: the bytes in flight per CU set the copy rate)
             const f32x4* src = P.afrag + (size_t)g0 * P.node_blocks * 64;
+#ifdef HIGSFA_DIAG
+            // timing experiment (HIGSFA_WHATIF bit 2; wrong results): no weight copy at all — what hiding it could gain at most
+            const int nvec = (P.whatif & 4) ? 0 : gn * P.node_blocks * 64;
+#else
             const int nvec = gn * P.node_blocks * 64;
+#endif
             int i = tid;
             for (; i + 7 * nthr < nvec; i += 8 * nthr) {
                 f32x4 v[8];

@@ -242,7 +242,10 @@ int hg_gauss_regression_multi_device(hg_gauss* const* gs, int m, const void* x, 
         if (n < 0 || n > 0x7fffffffll) hg::fail(HG_ERR_ARG, "bad row count");
         if (out_stride < n) hg::fail(HG_ERR_ARG, "out_stride %lld < n %lld", (long long)out_stride, (long long)n);
         if (x_dtype != HG_F32 && x_dtype != HG_F64) hg::fail(HG_ERR_ARG, "feature dtype must be HG_F32 or HG_F64");
-        bool wg = getenv("HIGSFA_GAUSS_WAVE") == nullptr, r4 = n >= 256;
+        // four rows per workgroup as soon as the launch has a chip's worth of workgroups WITHOUT it (m classifiers multiply the grid): at
+        // one row per workgroup every workgroup pulls its classifier's K d d matrices (160 KB for the 50 x 20 pose regressors) through L2
+        // for a single feature vector — 130 rows x 4 classifiers took 23.5 us that way, 348 x 4 at four rows per workgroup 14.5
+        bool wg = getenv("HIGSFA_GAUSS_WAVE") == nullptr, r4 = n * (int64_t)m >= 128;
         size_t kd_max = 0;
         for (int s = 0; s < m; ++s) {
             if (!gs[s]) hg::fail(HG_ERR_ARG, "null classifier handle");
@@ -262,16 +265,31 @@ int hg_gauss_regression_multi_device(hg_gauss* const* gs, int m, const void* x, 
         }
         GaussMulti M;
         for (int s = 0; s < m; ++s) M.g[s] = hg::gauss_params(gs[s]);
-        const int R = r4 ? 4 : 1;
+        // eight rows per workgroup where the batch has them (every workgroup streams its classifier's matrices through L2 once for its
+        // rows: 348 rows x 4 pose regressors moved 56 MB at four rows per workgroup and took 14 us whatever the batch)
+        // (measured and not used, round 5: 16.0-17.9 us per launch against 14.1-15.2 at four rows — the launch is bound by the chain of
+        // fp64 FMAs per thread, not by L2; the instantiation stays for HIGSFA_GAUSS_R8=1)
+        const bool r8 = r4 && n >= 64 && kd_max <= 2048 && getenv("HIGSFA_GAUSS_R8") != nullptr;
+        const int R = r8 ? 8 : r4 ? 4 : 1;
         const size_t lds = (size_t)R * (64 + kd_max) * 8;
         const dim3 grid((unsigned)((n + R - 1) / R), (unsigned)m);
         hipStream_t st = (hipStream_t)stream;
-#define HG_GAUSS_WGM(TT, RR) hipLaunchKernelGGL((k_gauss_regression_wg_multi<TT, RR>), grid, dim3(256), lds, st, (const TT*)x, ldx, n, M, out_reg, out_stride)
+#define HG_GAUSS_WGM(TT, RR)                                                                                                                  \
+    do {                                                                                                                                       \
+        if (lds > 64 * 1024) {                                                                                                                 \
+            static bool raised = false;      /* once per instantiation */                                                                      \
+            if (!raised) HG_HIP(hipFuncSetAttribute((const void*)k_gauss_regression_wg_multi<TT, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            raised = true;                                                                                                                     \
+        }                                                                                                                                      \
+        hipLaunchKernelGGL((k_gauss_regression_wg_multi<TT, RR>), grid, dim3(256), lds, st, (const TT*)x, ldx, n, M, out_reg, out_stride);     \
+    } while (0)
         if (x_dtype == HG_F32) {
-            if (r4) HG_GAUSS_WGM(float, 4);
+            if (r8) HG_GAUSS_WGM(float, 8);
+            else if (r4) HG_GAUSS_WGM(float, 4);
             else HG_GAUSS_WGM(float, 1);
         } else {
-            if (r4) HG_GAUSS_WGM(double, 4);
+            if (r8) HG_GAUSS_WGM(double, 8);
+            else if (r4) HG_GAUSS_WGM(double, 4);
             else HG_GAUSS_WGM(double, 1);
         }
 #undef HG_GAUSS_WGM

@@ -58,9 +58,10 @@ __device__ __forceinline__ void gauss_rows_wg(const T* __restrict__ x, int64_t l
         for (int r = 0; r < R; ++r) term[r * kd + e] = t[r];
     }
     __syncthreads();
-    if (wave < R && row0 + wave < n) {
-        const double* xr = xs + wave * 64;
-        const double* tr = term + wave * kd;
+    for (int rr = wave; rr < R; rr += (int)(blockDim.x >> 6)) {      // wave w finishes rows w, w + 4, ... of the workgroup's R (R <= 4: one each)
+        if (row0 + rr >= n) break;
+        const double* xr = xs + rr * 64;
+        const double* tr = term + rr * kd;
         double lmax = -INFINITY;
         double lp[kGaussMaxClasses / 64];
 #pragma unroll
@@ -95,8 +96,8 @@ __device__ __forceinline__ void gauss_rows_wg(const T* __restrict__ x, int64_t l
         }
         if (lane == 0) {
             const double reg = swa / sw;
-            out_reg[row0 + wave] = reg;
-            if (out_std) out_std[row0 + wave] = sqrt(fmax(swa2 / sw - reg * reg, 0.0));
+            out_reg[row0 + rr] = reg;
+            if (out_std) out_std[row0 + rr] = sqrt(fmax(swa2 / sw - reg * reg, 0.0));
         }
     }
 }

@@ -163,9 +163,12 @@ def convert_node(obj, igsfa_lr_input=None, ignore_attrs=(), pair_prodsadj_readin
         scaling, magn, matrix = _IGSFA_SCALING[method], None, None
         if scaling == "matrix":
             if igsfa_matrix_orientation not in MATRIX_ORIENTATIONS:
-                raise ValueError("iGSFANode with QR_decomposition scaling: state igsfa_matrix_orientation='n@R.T' or 'n@R' (how the "
-                                 "pickled square matrix R meets the normalised slow features) — the rule lives in cuicuilco @9bfd242, "
-                                 "which is not available here, and the two give different features")
+                raise ValueError("iGSFANode (%d -> %d) with slow_feature_scaling_method='QR_decomposition': state "
+                                 "igsfa_matrix_orientation='n@R.T' or 'n@R' (CLI: --igsfa-matrix-orientation) — how the pickled square "
+                                 "matrix R meets the normalised slow features.  The rule lives in cuicuilco @9bfd242, which is not "
+                                 "available here, and the two give different features.  (Until round 3 such nodes were imported "
+                                 "silently as n@R.T: callers of convert_node / load_flow_pickle / pickle_to_blob that relied on that "
+                                 "pass igsfa_matrix_orientation='n@R.T' to keep the old result.)" % _dims(obj))
             matrix = np.asarray(_get(obj, "R"), dtype=np.float64)
             if matrix.ndim != 2 or matrix.shape[0] != matrix.shape[1]:
                 raise ValueError("iGSFANode: QR scaling matrix R of shape %r is not square" % (matrix.shape,))
@@ -226,8 +229,11 @@ def convert_flow_object(flow_obj, **kw):
 
 
 def load_flow_pickle(path, igsfa_lr_input=None, ignore_attrs=(), pair_prodsadj_reading=None, igsfa_matrix_orientation=None):
-    return convert_flow_object(load_stub_pickle(path), igsfa_lr_input=igsfa_lr_input, ignore_attrs=ignore_attrs,
-                               pair_prodsadj_reading=pair_prodsadj_reading, igsfa_matrix_orientation=igsfa_matrix_orientation)
+    try:
+        return convert_flow_object(load_stub_pickle(path), igsfa_lr_input=igsfa_lr_input, ignore_attrs=ignore_attrs,
+                                   pair_prodsadj_reading=pair_prodsadj_reading, igsfa_matrix_orientation=igsfa_matrix_orientation)
+    except ValueError as e:      # name the file: an integrator converting a directory of SavedNetworks needs to know which one wants which flag
+        raise ValueError("%s: %s" % (path, e)) from e
 
 
 def pickle_to_blob(path, igsfa_lr_input=None, ignore_attrs=(), pair_prodsadj_reading=None, igsfa_matrix_orientation=None):

@@ -284,6 +284,18 @@ def test_config3_full_pyramid_1080p(native_lib, nets):
     assert whole["n_windows"] == 1738 and list(whole["counts"]) == list(got["counts"]) and whole["rows_executed"] == got["rows_executed"]
     for key in ("coords", "angles", "orig_index", "confidence"):
         assert np.array_equal(whole[key], got[key]), key
+    # another frame of the same size: the index tables of the prescale and of the first-stage grid are reused (they depend on sizes
+    # only, hg_patcher_extract_keyed_device) — same answer as the path that rebuilds them from explicit windows
+    frame2 = np.ascontiguousarray(frame[::-1, ::-1])
+    f2dev = torch.from_numpy(frame2).cuda()
+    again = dc.detect_frame(f2dev, smallest_face=0.1)
+    small2 = dc.prescale(f2dev)
+    assert np.array_equal(small2.cpu().numpy(), np.asarray(Image.fromarray(frame2, "L").resize((1000, 562), Image.NEAREST)))
+    explicit = dc.detect(small2, smallest_face=0.1, windows=(boxes, level))
+    assert list(again["counts"]) == list(explicit["counts"]) and again["counts"] != got["counts"]
+    for key in ("coords", "angles", "orig_index", "confidence"):
+        assert np.array_equal(again[key], explicit[key]), key
+    assert np.array_equal(dc.detect_frame(fdev, smallest_face=0.1)["coords"], got["coords"])
 
     def extract(coords, dang):
         return pt.extract(small, coords, (128, 128), dtype=np.uint8, delta_angs=dang) if len(coords) else np.zeros((0, 16384), np.uint8)
