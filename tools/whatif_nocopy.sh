@@ -1,4 +1,4 @@
-# Timing experiment (HIGSFA_DIAG build, tools/ab/libhigsfa_diag.so; results WRONG): k_stage without its weight copy into LDS (HIGSFA_WHATIF=4)
+# Timing experiment (HIGSFA_DIAG build: tools/build_diag_lib.sh -> tools/ab/libhigsfa_diag.so; results WRONG): k_stage without its weight copy into LDS (HIGSFA_WHATIF=4)
 # beside the same build unchanged — what hiding the copy behind the first GEMM could gain at most.
 cd $GRAFT_REPO_ROOT
 export HIGSFA_LIB=$GRAFT_REPO_ROOT/tools/ab/libhigsfa_diag.so
