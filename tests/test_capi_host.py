@@ -72,7 +72,9 @@ def test_plans(native_lib, nets, monkeypatch):
 def test_u11l_128_plan(native_lib, nets):
     inf, desc = Flow(nets("U11L-128")).host_plan()
     assert inf.plan_kind == _capi.HG_PLAN_FUSED and inf.n_stages == 12
-    assert inf.flops_per_row == 11017088 and inf.padded_flops_per_row == 13731840
+    # issued work (round 5: <= 4-row tiles counted as the v_mfma_f32_4x4x1 they run on, 512 FLOP, not as 16 x 16 tiles: profiles/r05_issue_table.md)
+    assert inf.flops_per_row == 11017088 and inf.padded_flops_per_row == 12158976
+    assert "issued: 24576 x 16x16x4 + 0 x 4x4x1" in desc and "issued: 9216 x 16x16x4 + 9216 x 4x4x1" in desc
     assert inf.input_dim == 16384 and inf.output_dim == 60 and inf.n_top_nodes == 22
     # iGSFA variant: three ordinary (folded) layers, then wide nodes on the node kernel in its folded form
     inf, desc = Flow(nets("U11L-128", node_kind="igsfa")).host_plan()
@@ -253,3 +255,47 @@ def test_ordering_event_entry_points_reject_null(native_lib):
         native_lib.hg_event_destroy(h)
     else:
         assert rc == _capi.HG_ERR_DEVICE and b"no HIP device" in native_lib.hg_last_error()
+
+
+def test_level_table_is_the_host_grid_and_round5_entries_check_their_arguments(native_lib):
+    """Round 5, host side only (no GPU): the table of pyramid levels handed to hg_cascade_detect_levels_device describes exactly the
+    windows grid.frame_boxes builds — numpy.linspace positions i * (stop / (n - 1)) with the end point exact, the reference's box
+    formula (face_analysis.py:630-669) and the level constants, which is what k_cascade_init_grid evaluates on the device (bit for bit
+    there: tests/test_cascade.py) — and hg_cascade_grid_device counts them without touching a device; the new entries reject bad
+    arguments before any HIP call."""
+    from pyfaceanalysis_amd import grid
+    from pyfaceanalysis_amd.cascade import frame_levels, frame_windows
+    L = _capi.lib()
+    for fw, fh, sf, sub in ((1000, 562, 0.1, (128, 128)), (1000, 562, 0.2, (64, 64)), (160, 90, 0.3, (16, 16)), (133, 131, 0.9, (128, 128)), (40, 400, 0.5, (32, 32))):
+        boxes, level = frame_windows(fw, fh, sf, grid.FACE_PIPELINE, sub)
+        levels, n_levels, n0 = frame_levels(fw, fh, sf, grid.FACE_PIPELINE, sub)
+        assert n0 == len(boxes)
+        out_b, out_l = [], []
+        for k in range(n_levels):
+            v = levels[k]
+            lin = lambda j, num, stop: 0.0 if (num <= 1 or j == 0) else (stop if j == num - 1 else j * (stop / (num - 1)))
+            for iy in range(v.ny):
+                for ix in range(v.nx):
+                    x0, y0 = lin(ix, v.nx, v.x_stop), lin(iy, v.ny, v.y_stop)
+                    out_b.append((x0, y0, x0 + v.patch_w - 1, y0 + v.patch_h - 1))
+                    out_l.append((v.max_dx, v.max_dy, v.base_side))
+        assert np.array_equal(np.array(out_b), boxes) and np.array_equal(np.array(out_l), level), (fw, fh, sf, sub)
+        n = C.c_int64(-1)
+        assert L.hg_cascade_grid_device(0, levels, n_levels, None, None, 0, C.byref(n), None) == _capi.HG_OK and n.value == n0
+    assert L.hg_cascade_grid_device(0, levels, 0, None, None, 0, C.byref(n), None) == _capi.HG_ERR_ARG
+    assert L.hg_cascade_grid_device(0, levels, 33, None, None, 0, C.byref(n), None) == _capi.HG_ERR_ARG
+    levels[0].nx = 0
+    assert L.hg_cascade_grid_device(0, levels, 1, None, None, 0, C.byref(n), None) == _capi.HG_ERR_ARG
+    # the group regression: 1 .. 4 classifiers per launch, checked before anything else
+    hs = (C.c_void_p * 5)()
+    assert L.hg_gauss_regression_multi_device(hs, 5, None, _capi.HG_F32, 0, 20, None, 0, None) == _capi.HG_ERR_ARG
+    assert L.hg_gauss_regression_multi_device(hs, 0, None, _capi.HG_F32, 0, 20, None, 0, None) == _capi.HG_ERR_ARG
+    assert L.hg_gauss_regression_multi_device(hs, 2, None, _capi.HG_F32, 0, 20, None, 0, None) == _capi.HG_ERR_ARG      # null handles
+    # the probes and the transport query
+    t, d, tr = C.c_double(), C.c_int(), C.c_int()
+    assert L.hg_host_pack_probe(None, _capi.HG_F64, 10, 16, 16, 1, C.byref(t)) == _capi.HG_ERR_ARG
+    x = np.arange(64 * 48, dtype=np.float64).reshape(64, 48) % 256
+    assert L.hg_host_pack_probe(x.ctypes.data_as(C.c_void_p), _capi.HG_F64, 64, 48, 48, 2, C.byref(t)) == _capi.HG_OK and 0 < t.value < 1.0
+    assert L.hg_host_pack_probe(x.ctypes.data_as(C.c_void_p), _capi.HG_F64, 64, 40, 48, 2, C.byref(t)) == _capi.HG_ERR_ARG      # ldx < in_dim
+    assert L.hg_host_store_probe(0, 1024, 1, C.byref(t), C.byref(d)) == _capi.HG_ERR_ARG
+    assert L.hg_flow_host_transport(None, C.byref(tr)) == _capi.HG_ERR_ARG
