@@ -453,6 +453,9 @@ __global__ void __launch_bounds__(512, 4) k_stage(StageParams P) {
     const int npg = P.nodes_per_group;
     float* sb = (float*)(smem + (size_t)npg * P.node_blocks * 64);
     int2* stab = (int2*)(sb + npg * P.bias_floats);
+    // (Round 5: the lane-group sums of the 4x4-form tiles through LDS — rem4_total_lds, which takes 1.9 us off the front kernel — make THIS kernel
+    // slower, layer 2 91.8 -> 105.5 us: its LDS queue is full of A-fragment reads, and the reduction's reads wait behind them and its lgkmcnt(0)
+    // for all of them.  The permlane form stays here.)
 
     unsigned long long t_copy = 0, t_g1 = 0, t_tail = 0, t_all0 = 0;
     int n_it = 0;
@@ -1522,7 +1525,7 @@ public:
                     StageFn2 fn = direct ? pick_stage01d(x_dtype, false, wgq) : pick_stage01p(x_dtype, false, rem4, fspec);
                     const int thr01 = 64 * std::max(1, (s.max_chunk_nodes + 1) / 2);   // one wave per pair of layer-0 nodes
                     // LDS: the tile buffers of FT batch tiles (k_stage01p only) + 10 vectors of 16 floats (means, biases) per wave
-                    const size_t lds2 = direct ? (size_t)4 * 160 * 4 + 8 * 8 + 4 * 4
+                    const size_t lds2 = direct ? (size_t)4 * 160 * 4 + 32 * 4 + (size_t)4 * 256 * 4      // constants | ring + progress words | reduction scratch per wave
                                                : (size_t)(kDoubleBuffer01 ? 2 : 1) * FT * 16 * s.lds_stride * 4 + (size_t)(thr01 / 64) * 160 * 4 + 16;   // + tile-group queue slots
                     const int groups2 = (n_tiles + FT - 1) / FT;
                     int occ = 1;

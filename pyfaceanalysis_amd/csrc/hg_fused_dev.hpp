@@ -228,6 +228,18 @@ __device__ __forceinline__ float rem4_total(f32x4 d) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+// The same totals through LDS (round 5): the wave writes its four partial-sum registers lane-major (one ds_write_b128) and every lane reads the
+// register of ITS lane group from the four lane groups (four conflict-free ds_read_b32), then (v0 + v1) + (v2 + v3) — rem4_total's operands and
+// association, hence its bits.  LDS instructions do not go through the port the MFMAs share with the vector ALU; the three permlane swaps
+// do, at ~19 cycles each (tools/ubench/mfma_loop.hip V6 / V8: 65 against 41 cycles per reduction with every wave of a SIMD reducing at once).
+// scratch: 256 floats of this wave's own.
+__device__ __forceinline__ float rem4_total_lds(f32x4 d, float* scratch, int lane) {
+    *(f32x4*)(scratch + lane * 4) = d;
+    const int g = lane >> 4, j = lane & 15;
+    const float v0 = scratch[(0 * 16 + j) * 4 + g], v1 = scratch[(1 * 16 + j) * 4 + g], v2 = scratch[(2 * 16 + j) * 4 + g], v3 = scratch[(3 * 16 + j) * 4 + g];
+    return (v0 + v1) + (v2 + v3);
+}
+
 // acc (a remainder tile's accumulator: row g of the tile = register 0 of lane group g) += the 4x4-form partial sums d
 __device__ __forceinline__ void add_rem4(f32x4& acc, f32x4 d) { acc[0] += rem4_total(d); }
 
@@ -297,7 +309,7 @@ __device__ __forceinline__ float* packed_slot_ptr(const StageParams& P, int tile
 // FS: the expansion is (identity, |x|^p) and known at compile time (as in the front kernel): no function loop, no kind branches.
 template <int MT1, int MT2, int T, bool REM = false, bool FS = false, typename WP, typename BP>
 __device__ __forceinline__ void node_tail(const StageParams& P, WP wA2, BP b2, int node, f32x4 (&z)[MT1][T],
-                                          const int (&tile)[T], int lane) {
+                                          const int (&tile)[T], int lane, float* rscr = nullptr) {      // rscr: this wave's 256 floats for rem4_total_lds (REM)
     const int g = lane >> 4;
     const int out_blk = node * P.mto;
 #ifdef HIGSFA_DIAG
@@ -376,7 +388,10 @@ __device__ __forceinline__ void node_tail(const StageParams& P, WP wA2, BP b2, i
     }
     if constexpr (REM) {
 #pragma unroll
-        for (int t = 0; t < T; ++t) add_rem4(y[MT2 - 1][t], d4[t]);
+        for (int t = 0; t < T; ++t) {
+            if (rscr) y[MT2 - 1][t][0] += rem4_total_lds(d4[t], rscr, lane);
+            else add_rem4(y[MT2 - 1][t], d4[t]);
+        }
         if (P.pack_base > 0) {      // full tiles as blocks; the remainder rows into this node's register of the shared block
 #pragma unroll
             for (int mt = 0; mt < MT2 - 1; ++mt)

@@ -595,9 +595,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ci = blockIdx.x % P.n_chunks, part = blockIdx.x / P.n_chunks;
     const DChunk ck = P.chunks[ci];
-    // LDS: 4 x 160 floats of per-wave constants | ring of 8 {pass, tile} | progress word per wave
+    // LDS: 4 x 160 floats of per-wave constants | ring of 8 {pass, tile} | progress word per wave | (HG_REM4_LDS) 256 floats of scratch per wave
     unsigned long long* const ring = (unsigned long long*)((float*)smem + 4 * 160);      // entry = pass << 32 | tile
     int* const prog = (int*)(ring + 8);
+#ifndef HG_REM4_LDS
+#define HG_REM4_LDS 1      // (A/B switch) lane-group sums of the 4x4-form tiles through LDS instead of permlane swaps
+#endif
+    float* const rscr = (float*)smem + 4 * 160 + 32 + wave * 256;
     if (WGQ) {
         if (tid < 8) ring[tid] = ~0ull;
         if (tid < 4) prog[tid] = 0;
@@ -805,7 +809,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
                 z1[0] = MFMA16(q_a1[kb][0][r], y0[kb][r], z1[0]);
                 d4 = MFMA4(q_a1[kb][1][r], y0[kb][r], d4);
             }
-        add_rem4(z1[1], d4);
+        if constexpr (HG_REM4_LDS) z1[1][0] += rem4_total_lds(d4, rscr, lane);
+        else add_rem4(z1[1], d4);
         d4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int fi = 0; fi < 2; ++fi) {
@@ -822,7 +827,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
             y1[0] = MFMA16(q_a2t[fi][0], e0, y1[0]);
             d4 = MFMA4(q_a2t[fi][1], e0, d4);
         }
-        add_rem4(y1[1], d4);
+        if constexpr (HG_REM4_LDS) y1[1][0] += rem4_total_lds(d4, rscr, lane);
+        else add_rem4(y1[1], d4);
         st_y0 = y1[0];
         st_y1 = y1[1][0];
         st_tile = tile;

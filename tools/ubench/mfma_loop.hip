@@ -16,6 +16,16 @@ __device__ __forceinline__ float rem4_total(f32x4 d) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+// The same reduce-scatter through LDS (round 5): the wave writes its four partial-sum registers lane-major (one ds_write_b128) and every lane reads
+// the register of ITS lane group from the four lane groups (four conflict-free ds_read_b32), then (v0 + v1) + (v2 + v3) — the operands and the
+// association of rem4_total, hence the same bits — with three vector adds instead of three permlane swaps + three adds on the port the MFMAs need.
+__device__ __forceinline__ float rem4_total_lds(f32x4 d, float* scratch, int lane) {
+    *(f32x4*)(scratch + lane * 4) = d;
+    const int g = lane >> 4, j = lane & 15;
+    const float v0 = scratch[(0 * 16 + j) * 4 + g], v1 = scratch[(1 * 16 + j) * 4 + g], v2 = scratch[(2 * 16 + j) * 4 + g], v3 = scratch[(3 * 16 + j) * 4 + g];
+    return (v0 + v1) + (v2 + v3);
+}
+
 // MT = 4 m-tiles, T = 2 batch tiles -> 8 accumulators, 32 MFMAs per "K-block" iteration
 template <int V>
 __global__ void __launch_bounds__(512) k(const f32x4* __restrict__ w, const int2* __restrict__ tab, float* out, int iters, int nk_in) {
@@ -48,7 +58,7 @@ __global__ void __launch_bounds__(512) k(const f32x4* __restrict__ w, const int2
             const int kn = (it + 1) & 15;
             for (int m = 0; m < 4; ++m) an[m] = wl[(kn * 4 + m) * 64];
         }
-        if (V == 6 || V == 7) {
+        if (V == 6 || V == 7 || V == 8) {
             // Round 5: a 60-row affine as 3 full m-tiles on the 16x16x4 form + its 12-row tail as three 4-row
             // groups on v_mfma_f32_4x4x1 (8 cycles each instead of a fourth 32-cycle tile), the tail's A values read from a compact
             // LDS image (16 distinct 16-byte words per group: lanes with the same (g, i) read the same word) and the three
@@ -71,12 +81,13 @@ __global__ void __launch_bounds__(512) k(const f32x4* __restrict__ w, const int2
 #pragma unroll
                     for (int t = 0; t < 2; ++t) d4[q][t] = MFMA4(a4[q][r], bf[t][r], d4[q][t]);
             }
-            if (V == 6 && (it % 12) == 11) {
+            if ((V == 6 || V == 8) && (it % 12) == 11) {
+                float* scratch = (float*)(smem + 4096 + 64) + (tid >> 6) * 256;
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
 #pragma unroll
                     for (int q = 0; q < 3; ++q) {
-                        acc[3][t][q] += rem4_total(d4[q][t]);
+                        acc[3][t][q] += V == 8 ? rem4_total_lds(d4[q][t], scratch, lane) : rem4_total(d4[q][t]);
                         d4[q][t] = f32x4{0, 0, 0, 0};
                     }
                 }
@@ -118,7 +129,7 @@ template <int V>
 void run(const char* name, const f32x4* w, const int2* tab, float* out, int threads, int blocks_per_cu) {
     const int iters = 4096;
     const int blocks = 256 * blocks_per_cu;
-    size_t lds = 4096 * 16 + 64 * 8;
+    size_t lds = 4096 * 16 + 64 * 16 + 8 * 1024;
     hipFuncSetAttribute((const void*)k<V>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
@@ -150,6 +161,7 @@ int main(int argc, char** argv) {
         run<5>("V5 V4 with m-tile outer, k-step inner", w, tab, out, thr, per);
         run<6>("V6 V4, 12-row tail as 3 x 4x4x1 + reduce", w, tab, out, thr, per);
         run<7>("V7 V6 without the reduce-scatters", w, tab, out, thr, per);
+        run<8>("V8 V6, reduce-scatters through LDS", w, tab, out, thr, per);
     }
     return 0;
 }
