@@ -51,6 +51,7 @@ struct FusedOptions {
     bool no_direct = false;       // HIGSFA_NO_DIRECT: front kernel always stages the input rows through LDS (k_stage01p)
     int tail_max = 3;             // HIGSFA_TAIL: most layers k_tail fuses at the top of the hierarchy (0: off — per-layer launches + k_unpack)
     bool no_fspec = false;        // HIGSFA_NO_FSPEC: front kernel without the compile-time (identity, abs-power) expansion
+    int subtree_max_tiles = 32;   // HIGSFA_SUBTREE: batches of up to this many 16-row tiles run the layers below the top as sub-trees (k_subtree); 0: never
     int splitm_max_nodes = 4;     // experiments: HIGSFA_SPLITM_MAX
     int splitm_max_wgs = 512;     // HIGSFA_SPLITM_WGS: largest k_stage_splitm grid for layers of more than splitm_max_nodes nodes
     int shape_variant = 0;        // experiments: HIGSFA_SHAPES
@@ -72,6 +73,7 @@ struct FusedOptions {
         if (const char* e = getenv("HIGSFA_SPLITM_MAX")) o.splitm_max_nodes = atoi(e);
         if (const char* e = getenv("HIGSFA_SPLITM_WGS")) o.splitm_max_wgs = atoi(e);
         if (const char* e = getenv("HIGSFA_SHAPES")) o.shape_variant = atoi(e);
+        if (const char* e = getenv("HIGSFA_SUBTREE")) o.subtree_max_tiles = std::max(0, atoi(e));
         if (const char* e = getenv("HIGSFA_TAIL")) o.tail_max = std::max(0, std::min(atoi(e), kMaxTail));
         return o;
     }
@@ -962,6 +964,10 @@ struct HostStage {
     int pk_kbi = -1;            // ... and sit at this position of every node's K-block list
     std::vector<int32_t> pack_slot;
     DevBuf d_pack_slot;
+    // k_subtree (short batches): [sub-tree][position] -> node of this layer, and the K-block table with source blocks renumbered
+    // to the sub-tree's own activation buffer in LDS (position of the source node in the layer below x mto + tile)
+    std::vector<int32_t> sub_nodes, sub_kb1tab;
+    DevBuf d_sub_nodes, d_sub_kb1tab;
     bool has_exp = false, contig4 = false, vec_ok = false;
     std::vector<ExpFunc> funcs;
     uint8_t nk2[kMaxMT][kMaxFuncs] = {};
@@ -1299,6 +1305,7 @@ public:
         for (auto& hs : stages_)      // k_tail reads 8 K-block entries at once from a node's first: 8 spare ones behind the last node's
             if (!hs.kb1tab.empty()) hs.kb1tab.resize(hs.kb1tab.size() + 16, 0);
         plan_tail();
+        plan_subtree();
     }
 
     int plan_kind() const override { return HG_PLAN_FUSED; }
@@ -1330,6 +1337,8 @@ public:
             if (!s.gcol.empty()) s.d_gcol.upload(s.gcol.data(), s.gcol.size() * 4);
             if (!s.etab.empty()) s.d_etab.upload(s.etab.data(), s.etab.size() * 4);
             if (!s.pack_slot.empty()) s.d_pack_slot.upload(s.pack_slot.data(), s.pack_slot.size() * 4);
+            if (!s.sub_nodes.empty()) s.d_sub_nodes.upload(s.sub_nodes.data(), s.sub_nodes.size() * 4);
+            if (!s.sub_kb1tab.empty()) s.d_sub_kb1tab.upload(s.sub_kb1tab.data(), s.sub_kb1tab.size() * 4);
             if (!s.chunks.empty()) {
                 s.d_chunks.upload(s.chunks.data(), s.chunks.size() * sizeof(DChunk));
                 s.d_runs.upload(s.runs.data(), s.runs.size() * sizeof(DRun));
@@ -1413,6 +1422,15 @@ public:
                     for (size_t k = si; k <= stages_.size(); ++k) HG_HIP(hipEventRecord(ev[e++], st));   // the first event carries the launch's time
                 HG_HIP(hipGetLastError());
                 return;
+            }
+            if ((int)si == sub_begin_ && n_tiles <= opt_.subtree_max_tiles) {
+                // a short batch: these layers as independent sub-trees in one launch (hg_fused_tail.hip)
+                launch_subtree(subtree_params(cur, nxt, n_tiles), st);
+                std::swap(cur, nxt);
+                if (ev)
+                    for (int k = 0; k < sub_len_; ++k) HG_HIP(hipEventRecord(ev[e++], st));   // the first event carries the launch's time
+                si += sub_len_ - 1;
+                continue;
             }
             StageParams P = base_params(s, cur, nxt);
             if (s.kind == 1) {        // row-major input -> fragment order
@@ -1773,7 +1791,7 @@ public:
         d_col_of_.free();
         for (auto& s : stages_) {
             s.d_afrag.free(); s.d_bias.free(); s.d_kb1tab.free(); s.d_chunks.free();
-            s.d_runs.free(); s.d_piece.free(); s.d_koff.free(); s.d_kmean.free(); s.d_kcol.free(); s.d_gcol.free(); s.d_etab.free(); s.d_pack_slot.free();
+            s.d_runs.free(); s.d_piece.free(); s.d_koff.free(); s.d_kmean.free(); s.d_kcol.free(); s.d_gcol.free(); s.d_etab.free(); s.d_pack_slot.free(); s.d_sub_nodes.free(); s.d_sub_kb1tab.free();
         }
         cap_rows_ = 0;
     }
@@ -2528,6 +2546,131 @@ private:
                                       : "  [in the top-of-hierarchy launch]";
     }
 
+    // Layers below the top that fall into independent sub-trees (k_subtree, hg_fused_tail.hip): the run of up to three ordinary
+    // layers that ends just below the top-of-hierarchy launch of a short batch, if the nodes each root (node of the run's last
+    // layer) draws on, layer by layer, are as many for every root and shared with no other root.
+    void plan_subtree() {
+        sub_begin_ = -1;
+        if (opt_.subtree_max_tiles <= 0) return;
+        const int ns = (int)stages_.size();
+        // (the layer under a short batch's k_tail launch runs alone: tail_start)
+        const int end = tail_begin_ < 0 ? ns : (ns - tail_begin_ >= 3 ? tail_begin_ + 1 : tail_begin_) - 1;
+        for (int last = end - 1; last >= 2; --last) {
+            const int k = stages_[last].n_nodes;
+            if (k < 8) continue;      // fewer workgroups per tile than XCDs: per-layer launches keep more of the chip busy
+            int b = last + 1, act_blocks = 0, e_blocks = 0;
+            std::vector<std::vector<int32_t>> members(kMaxTail), tabs(kMaxTail);      // by distance from `last`
+            while (b > (fuse01_ ? 2 : 1) && last + 1 - b < kMaxTail) {
+                const HostStage& s = stages_[b - 1];
+                if (s.kind != 0 || s.from_x || s.rem4 || s.pack_out || s.nf > kMaxFuncs || s.n_nodes % k) break;
+                if (s.has_exp && s.mt1 * s.nf > 8) break;
+                const int per = s.n_nodes / k;
+                if (per * (s.has_exp ? std::max(s.mt1, s.mt2) : s.mt1) > 16) break;
+                std::vector<int32_t> mem((size_t)k * per, -1), tab;
+                if (b - 1 == last) {
+                    for (int j = 0; j < k; ++j) mem[j] = j;
+                } else {
+                    // nodes of this layer under each root, in the order the layer above first reads them
+                    const HostStage& up = stages_[b];
+                    const std::vector<int32_t>& mup = members[last - b];
+                    const int per_up = up.n_nodes / k;
+                    std::vector<int32_t> owner(s.n_nodes, -1), pos(s.n_nodes, -1);
+                    bool ok = s.nb_out == s.n_nodes * s.mto;
+                    tab.assign(up.kb1tab.size(), 0);
+                    for (int j = 0; j < k && ok; ++j) {
+                        int have = 0;
+                        for (int q = 0; q < per_up && ok; ++q) {
+                            const int ni = mup[(size_t)j * per_up + q];
+                            for (int kb = 0; kb < up.kb1 && ok; ++kb) {
+                                const size_t at = ((size_t)ni * up.kb1 + kb) * 2;
+                                const int src = up.kb1tab[at];
+                                if (src < 0 || src >= s.nb_out) { ok = false; break; }
+                                const int sn = src / s.mto;
+                                if (owner[sn] < 0) {
+                                    if (have == per) { ok = false; break; }
+                                    owner[sn] = j;
+                                    pos[sn] = have;
+                                    mem[(size_t)j * per + have++] = sn;
+                                } else if (owner[sn] != j) {
+                                    ok = false;
+                                    break;
+                                }
+                                tab[at] = pos[sn] * s.mto + src % s.mto;
+                                tab[at + 1] = up.kb1tab[at + 1];
+                            }
+                        }
+                        if (have != per) ok = false;
+                    }
+                    if (!ok) break;
+                }
+                const int act = b - 1 < last ? std::max(act_blocks, per * s.mto) : act_blocks;
+                const int eb = std::max(e_blocks, s.has_exp ? per * s.nf * s.mt1 : 0);
+                if (((size_t)2 * act + eb) * 1024 > 150 * 1024) break;
+                act_blocks = act;
+                e_blocks = eb;
+                members[last - (b - 1)] = std::move(mem);
+                if (b - 1 < last) tabs[last - b] = std::move(tab);      // the table of the layer above this one
+                --b;
+            }
+            if (last + 1 - b < 2) continue;
+            sub_begin_ = b;
+            sub_len_ = last + 1 - b;
+            sub_n_ = k;
+            sub_act_blocks_ = act_blocks;
+            sub_e_blocks_ = e_blocks;
+            for (int i = b; i <= last; ++i) {
+                stages_[i].sub_nodes = members[last - i];
+                if (i > b) stages_[i].sub_kb1tab = tabs[last - i];
+                stages_[i].name += i == b ? "  [batches of up to " + std::to_string(opt_.subtree_max_tiles * 16) + " rows: this and the next " +
+                                                std::to_string(sub_len_ - 1) + " layer(s) as " + std::to_string(k) + " sub-trees in ONE launch]"
+                                          : "  [in the sub-tree launch for short batches]";
+            }
+            return;
+        }
+    }
+
+    static void fill_tail_stage(TailStage& S, HostStage& hs) {
+        S.afrag = (const f32x4*)hs.d_afrag.p;
+        S.bias = (const float*)hs.d_bias.p;
+        S.kb1tab = (const int2*)hs.d_kb1tab.p;
+        S.n_nodes = hs.n_nodes;
+        S.kb1 = hs.kb1;
+        S.nf = hs.nf;
+        S.has_exp = hs.has_exp ? 1 : 0;
+        S.node_blocks = hs.node_blocks;
+        S.bias_floats = hs.bias_floats;
+        S.nb_out = hs.nb_out;
+        S.mto = hs.mto;
+        S.mt1 = hs.mt1;
+        S.mt2 = hs.mt2;
+        for (int fi = 0; fi < hs.nf; ++fi) {
+            S.funcp |= (uint32_t)hs.funcs[fi].kind << (4 * fi);
+            S.expo[fi] = (float)hs.funcs[fi].expo;
+            for (int mt1 = 0; mt1 < hs.mt1; ++mt1) S.nk2p[mt1] |= (uint32_t)hs.nk2[mt1][fi] << (4 * fi);
+        }
+    }
+
+    TailParams subtree_params(const f32x4* in, f32x4* out, int n_tiles) {
+        TailParams TP{};
+        TP.n_stages = sub_len_;
+        for (int k = 0; k < sub_len_; ++k) {
+            HostStage& hs = stages_[sub_begin_ + k];
+            fill_tail_stage(TP.st[k], hs);
+            TP.st[k].n_nodes /= sub_n_;
+            TP.sub_nodes[k] = (const int32_t*)hs.d_sub_nodes.p;
+            if (k > 0) TP.st[k].kb1tab = (const int2*)hs.d_sub_kb1tab.p;
+        }
+        TP.in = in;
+        TP.out_frag = out;
+        TP.n_sub = sub_n_;
+        TP.nb_out_frag = stages_[sub_begin_ + sub_len_ - 1].nb_out;
+        TP.n_tiles = n_tiles;
+        TP.nb_in = stages_[sub_begin_].nb_in;
+        TP.act_blocks = sub_act_blocks_;
+        TP.e_blocks = sub_e_blocks_;
+        return TP;
+    }
+
     // Three fused layers pay off from ~1400 rows on (call times against N, profiles/r03_call_times.txt: 16 waves per workgroup walk
     // the three layers' latencies one after the other — 23 us however small the batch, against 6 us for a k_stage_splitm launch of
     // the 4-node layer plus 13 us for the two layers above it); below that the launch starts one layer later.  Same bits either way.
@@ -2541,26 +2684,7 @@ private:
         const int ns = (int)stages_.size();
         TP.n_stages = ns - begin;
         for (int k = 0; k < TP.n_stages; ++k) {
-            HostStage& hs = stages_[begin + k];
-            TailStage& S = TP.st[k];
-            S.afrag = (const f32x4*)hs.d_afrag.p;
-            S.bias = (const float*)hs.d_bias.p;
-            S.kb1tab = (const int2*)hs.d_kb1tab.p;
-            S.n_nodes = hs.n_nodes;
-            S.kb1 = hs.kb1;
-            S.nf = hs.nf;
-            S.has_exp = hs.has_exp ? 1 : 0;
-            S.node_blocks = hs.node_blocks;
-            S.bias_floats = hs.bias_floats;
-            S.nb_out = hs.nb_out;
-            S.mto = hs.mto;
-            S.mt1 = hs.mt1;
-            S.mt2 = hs.mt2;
-            for (int fi = 0; fi < hs.nf; ++fi) {
-                S.funcp |= (uint32_t)hs.funcs[fi].kind << (4 * fi);
-                S.expo[fi] = (float)hs.funcs[fi].expo;
-                for (int mt1 = 0; mt1 < hs.mt1; ++mt1) S.nk2p[mt1] |= (uint32_t)hs.nk2[mt1][fi] << (4 * fi);
-            }
+            fill_tail_stage(TP.st[k], stages_[begin + k]);
         }
         TP.in = in;
         TP.y = y;
@@ -2606,6 +2730,7 @@ private:
     DevBuf d_col_base_, d_col_of_, bufA_, bufB_, stamp_buf_;
     int tail_begin_ = -1;         // first stage of the top-of-hierarchy launch (k_tail); -1: none
     int tail_act_blocks_ = 0, tail_e_blocks_ = 0;
+    int sub_begin_ = -1, sub_len_ = 0, sub_n_ = 0, sub_act_blocks_ = 0, sub_e_blocks_ = 0;      // k_subtree run (short batches); -1: none
     WorkQueue wq_front_, wq_direct_, wq_direct_wg_;
     int32_t* err_host_ = nullptr;
     int32_t* err_dev_ = nullptr;

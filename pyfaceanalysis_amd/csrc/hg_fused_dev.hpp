@@ -436,10 +436,16 @@ struct TailParams {
     int32_t y_cols, y_f64;
     int32_t n_stages, n_tiles, nb_in;
     int32_t act_blocks, e_blocks;      // LDS: two activation buffers of act_blocks x T KiB, one expansion buffer of e_blocks x T KiB
+    // k_subtree only: n_sub independent sub-trees of the fused layers, one per workgroup (st[k].n_nodes = nodes of ONE sub-tree in
+    // layer k, st[k > 0].kb1tab = source blocks numbered within the sub-tree's LDS buffer); the last fused layer's tiles go to out_frag in fragment order (nb_out_frag blocks per batch tile)
+    f32x4* out_frag;
+    const int32_t* sub_nodes[kMaxTail];      // per fused layer: [sub-tree][position] -> node of the layer
+    int32_t n_sub, nb_out_frag;
 };
 size_t tail_lds_bytes(const TailParams& P, int T);
 int tail_waves(const TailParams& P);
 void launch_tail(const TailParams& P, int T, hipStream_t st);
+void launch_subtree(const TailParams& P, hipStream_t st);
 
 
 typedef void (*StageFn)(StageParams);

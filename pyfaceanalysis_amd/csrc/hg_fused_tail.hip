@@ -27,18 +27,24 @@ namespace {
 
 constexpr int KB = 8;      // K-blocks loaded per batch (all of a 120-input node's)
 
+enum { OUT_LDS = 0, OUT_Y = 1, OUT_FRAG = 2 };
+
 // One layer for this workgroup's T tiles.  FIRST: inputs come from global memory (P.in), else from the LDS buffer `src`.
-// LAST: outputs go to the caller's y, else to the LDS buffer `dst` (block-major: block b of tile t at (b * T + t) * 64).
-template <int T, bool FIRST, bool LAST>
+// OUT_Y: outputs go to the caller's y; OUT_FRAG: to P.out_frag in fragment order; OUT_LDS: to the LDS buffer `dst` (block-major:
+// block b of tile t at (b * T + t) * 64).  k_subtree: the workgroup's nodes are nmap[0 .. S.n_nodes - 1] of the layer.
+template <int T, bool FIRST, int OUT>
 __device__ __forceinline__ void tail_layer(const TailParams& P, const TailStage& S, const f32x4* src, f32x4* dst, f32x4* ebuf,
-                                           const int (&tile)[T], const uint32_t (&trow)[T], int w, int lane) {
+                                           const int (&tile)[T], const uint32_t (&trow)[T], int w, int lane,
+                                           const int32_t* nmap = nullptr) {
+    constexpr bool LAST = OUT == OUT_Y;
     const int g = lane >> 4;
     const int wpn = S.has_exp ? (S.mt1 > S.mt2 ? S.mt1 : S.mt2) : S.mt1;      // waves per node
     const int node = w / wpn, mw = w - node * wpn;
     const bool on = node < S.n_nodes;
-    const f32x4* wnode = S.afrag + (size_t)(on ? node : 0) * S.node_blocks * 64 + lane;
-    const float* bnode = S.bias + (size_t)(on ? node : 0) * S.bias_floats + g * 4;
-    const int2* kt = S.kb1tab + (size_t)(on ? node : 0) * S.kb1;
+    const int gnode = nmap ? nmap[on ? node : 0] : on ? node : 0;      // (wave-uniform: a scalar load)
+    const f32x4* wnode = S.afrag + (size_t)gnode * S.node_blocks * 64 + lane;
+    const float* bnode = S.bias + (size_t)gnode * S.bias_floats + g * 4;
+    const int2* kt = S.kb1tab + (size_t)gnode * S.kb1;
     const int nf = S.nf, mt1n = S.mt1, mt2n = S.mt2;
     const int out_blk = node * S.mto + mw;
     // which caller column each of this lane's four values of the output tile goes to (LAST only)
@@ -70,6 +76,10 @@ __device__ __forceinline__ void tail_layer(const TailParams& P, const TailStage&
                         }
                 }
             }
+        } else if constexpr (OUT == OUT_FRAG) {
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+                if (tile[t] < P.n_tiles) P.out_frag[((size_t)tile[t] * P.nb_out_frag + gnode * S.mto + mw) * 64 + lane] = v[t];
         } else {
 #pragma unroll
             for (int t = 0; t < T; ++t) dst[((size_t)out_blk * T + t) * 64 + lane] = v[t];
@@ -169,7 +179,7 @@ __device__ __forceinline__ void tail_layer(const TailParams& P, const TailStage&
         }
         emit(y);
     }
-    if constexpr (!LAST) __syncthreads();      // this layer's output tiles are in LDS; ebuf is free again
+    if constexpr (OUT == OUT_LDS) __syncthreads();      // this layer's output tiles are in LDS; ebuf is free again
 }
 
 template <int T, int WAVES>
@@ -188,18 +198,53 @@ __global__ void __launch_bounds__(WAVES * 64) k_tail(TailParams P) {
     f32x4* act1 = smem + (size_t)P.act_blocks * T * 64;
     f32x4* ebuf = act1 + (size_t)P.act_blocks * T * 64;
     if (P.n_stages == 1) {
-        tail_layer<T, true, true>(P, P.st[0], nullptr, nullptr, ebuf, tile, trow, w, lane);
+        tail_layer<T, true, OUT_Y>(P, P.st[0], nullptr, nullptr, ebuf, tile, trow, w, lane);
     } else if (P.n_stages == 2) {
-        tail_layer<T, true, false>(P, P.st[0], nullptr, act0, ebuf, tile, trow, w, lane);
-        tail_layer<T, false, true>(P, P.st[1], act0, nullptr, ebuf, tile, trow, w, lane);
+        tail_layer<T, true, OUT_LDS>(P, P.st[0], nullptr, act0, ebuf, tile, trow, w, lane);
+        tail_layer<T, false, OUT_Y>(P, P.st[1], act0, nullptr, ebuf, tile, trow, w, lane);
     } else {
-        tail_layer<T, true, false>(P, P.st[0], nullptr, act0, ebuf, tile, trow, w, lane);
-        tail_layer<T, false, false>(P, P.st[1], act0, act1, ebuf, tile, trow, w, lane);
-        tail_layer<T, false, true>(P, P.st[2], act1, nullptr, ebuf, tile, trow, w, lane);
+        tail_layer<T, true, OUT_LDS>(P, P.st[0], nullptr, act0, ebuf, tile, trow, w, lane);
+        tail_layer<T, false, OUT_LDS>(P, P.st[1], act0, act1, ebuf, tile, trow, w, lane);
+        tail_layer<T, false, OUT_Y>(P, P.st[2], act1, nullptr, ebuf, tile, trow, w, lane);
     }
 }
 
-template <int T>
+// k_subtree: two or three layers BELOW the top as one launch for short batches.  Where the receptive fields tile the layer
+// below without overlap (every node of a layer is read by exactly one node of the next: all through the upper half of the preset
+// hierarchies), the fused layers fall into n_sub independent sub-trees (the planner lists each one's nodes: plan_subtree); a workgroup takes one sub-tree for one batch tile the way k_tail
+// takes the whole top, and writes the sub-tree's root tiles back in fragment order.  A short batch (one 1080p frame's later
+// cascade stages: 18 .. 348 windows) leaves every per-layer launch at its floor of 9-12 us; this replaces three of them.
+// Consecutive workgroups are the sub-trees of one tile, so with 8 sub-trees each XCD's L2 holds the weights of one.
+template <int T, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) k_subtree(TailParams P) {
+    extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int sub = blockIdx.x % P.n_sub, tb = blockIdx.x / P.n_sub;
+    int tile[T];
+    uint32_t trow[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        tile[t] = tb * T + t;
+        trow[t] = (uint32_t)(tile[t] < P.n_tiles ? tile[t] : tile[0]) * (uint32_t)P.nb_in;
+    }
+    f32x4* act0 = smem;
+    f32x4* act1 = smem + (size_t)P.act_blocks * T * 64;
+    f32x4* ebuf = act1 + (size_t)P.act_blocks * T * 64;
+    const int32_t* m0 = P.sub_nodes[0] + sub * P.st[0].n_nodes;
+    const int32_t* m1 = P.sub_nodes[1] + sub * P.st[1].n_nodes;
+    if (P.n_stages == 2) {
+        tail_layer<T, true, OUT_LDS>(P, P.st[0], nullptr, act0, ebuf, tile, trow, w, lane, m0);
+        tail_layer<T, false, OUT_FRAG>(P, P.st[1], act0, nullptr, ebuf, tile, trow, w, lane, m1);
+    } else {
+        const int32_t* m2 = P.sub_nodes[2] + sub * P.st[2].n_nodes;
+        tail_layer<T, true, OUT_LDS>(P, P.st[0], nullptr, act0, ebuf, tile, trow, w, lane, m0);
+        tail_layer<T, false, OUT_LDS>(P, P.st[1], act0, act1, ebuf, tile, trow, w, lane, m1);
+        tail_layer<T, false, OUT_FRAG>(P, P.st[2], act1, nullptr, ebuf, tile, trow, w, lane, m2);
+    }
+}
+
+template <int T, bool SUB = false>
 void launch_t(const TailParams& P, int waves, unsigned grid, size_t lds, hipStream_t st) {
     auto go = [&](auto fn) {
         if (lds > 64 * 1024) {      // raise the dynamic-LDS limit once per (device, function)
@@ -214,9 +259,14 @@ void launch_t(const TailParams& P, int waves, unsigned grid, size_t lds, hipStre
         }
         hipLaunchKernelGGL(fn, grid, waves * 64, lds, st, P);
     };
-    if (waves <= 4) go(k_tail<T, 4>);
-    else if (waves <= 8) go(k_tail<T, 8>);
-    else go(k_tail<T, 16>);
+    if constexpr (SUB) {
+        if (waves <= 8) go(k_subtree<T, 8>);
+        else go(k_subtree<T, 16>);
+    } else {
+        if (waves <= 4) go(k_tail<T, 4>);
+        else if (waves <= 8) go(k_tail<T, 8>);
+        else go(k_tail<T, 16>);
+    }
 }
 
 }  // namespace
@@ -238,6 +288,13 @@ void launch_tail(const TailParams& P, int T, hipStream_t st) {
     const size_t lds = tail_lds_bytes(P, T);
     if (T == 2) launch_t<2>(P, waves, grid, lds, st);
     else launch_t<1>(P, waves, grid, lds, st);
+    HG_HIP(hipGetLastError());
+}
+
+void launch_subtree(const TailParams& P, hipStream_t st) {
+    if (P.n_stages < 2 || P.n_sub < 1) fail(HG_ERR_STATE, "k_subtree: two or three layers, at least one sub-tree");
+    const int waves = tail_waves(P);
+    launch_t<1, true>(P, waves, (unsigned)P.n_sub * (unsigned)P.n_tiles, tail_lds_bytes(P, 1), st);
     HG_HIP(hipGetLastError());
 }
 

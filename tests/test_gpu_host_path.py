@@ -179,10 +179,10 @@ def test_top_of_hierarchy_launch(native_lib, nets, monkeypatch):
         flows[depth] = Flow(nodes, output_dtype=np.float32)
         desc = flows[depth].describe()
         assert ("no unpack pass" in desc) == (depth != "0")
-        assert ("ONE launch" in desc) == (depth in ("2", "3"))
+        assert ("ONE launch, activations in LDS" in desc) == (depth in ("2", "3"))
     monkeypatch.delenv("HIGSFA_TAIL")
     default = Flow(nodes, output_dtype=np.float32)
-    assert "ONE launch" in default.describe()
+    assert "ONE launch, activations in LDS" in default.describe()
     base = flows["0"].execute(x)
     assert base.shape == (1100, 60)
     ref = oracle.execute_flow(nodes, x[:33])
@@ -230,6 +230,65 @@ def test_top_of_hierarchy_launch_other_nets(native_lib, nets, monkeypatch, maker
     print(maker, [ln for ln in fused.describe().splitlines() if "launch" in ln or "unpack" in ln][-2:])
     per_layer.close()
     fused.close()
+
+
+@pytest.mark.parametrize("preset", ["U11L-128", "U11L-64"])
+def test_subtree_launch_for_short_batches(native_lib, nets, monkeypatch, preset):
+    """Short batches (up to 512 rows; a frame's later cascade stages hold 18 .. 348 windows) run layers 5-7 of the 11-layer nets
+    (32, 16, 8 nodes) as eight independent sub-trees in ONE launch (k_subtree, hg_fused_tail.hip; HIGSFA_SUBTREE = largest batch
+    in 16-row tiles, 0 = never).  Same products in the same order as the per-layer kernels: the same bits with the launch off,
+    at its default and forced on for long batches, for ragged batches and for both output types; and the sub-trees the planner
+    found are the eight roots' own (the nodes a root reads are not consecutive in every layer)."""
+    nodes = nets(preset)
+    side = 128 if preset == "U11L-128" else 64
+    x = synth.make_subimages(1300, side, dtype=np.uint8)
+    monkeypatch.setenv("HIGSFA_SUBTREE", "0")
+    off = Flow(nodes, output_dtype=np.float32)
+    assert "sub-trees in ONE launch" not in off.describe()      # (the plan is made, and the environment read, at first use)
+    monkeypatch.setenv("HIGSFA_SUBTREE", "100000")
+    forced = Flow(nodes, output_dtype=np.float32)
+    d_forced = forced.describe()
+    monkeypatch.delenv("HIGSFA_SUBTREE")
+    default = Flow(nodes, output_dtype=np.float32)
+    for d in (d_forced, default.describe()):
+        assert "as 8 sub-trees in ONE launch" in d and d.count("[in the sub-tree launch for short batches]") == 2
+    base = off.execute(x)
+    assert rel_err(base[:40], oracle.execute_flow(nodes, x[:40])) <= TOL
+    for name, f in (("default", default), ("forced", forced)):
+        for n in (1, 16, 17, 18, 44, 130, 348, 512, 513, 1, 1300, 700):
+            assert np.array_equal(f.execute(x[:n]), base[:n]), (name, n)
+        assert np.array_equal(f.execute(x[:130], n_cols=20), base[:130, :20]), name
+    f64 = Flow(nodes)
+    assert np.array_equal(f64.execute(x[:348], n_cols=20), base[:348, :20].astype(np.float64))
+    # benchmark= timings: one entry per stage as ever; the three layers' time is carried by the first of them
+    class Bench(object):
+        enabled = True
+
+        def __init__(self):
+            self.tasks = []
+
+        def add_task_ellapsed(self, label, secs, reference=None):
+            self.tasks.append((label, secs))
+
+    b = Bench()
+    assert np.array_equal(default.execute(x[:130], benchmark=b), base[:130])
+    assert len(b.tasks) == default.info().n_stages
+    sub = [t for t in b.tasks if "sub-tree" in t[0]]
+    assert len(sub) == 3 and sub[0][1] > 0 and sub[1][1] < sub[0][1] and sub[2][1] < sub[0][1]
+    for f in (off, forced, default, f64):
+        f.close()
+
+
+def test_subtree_launch_is_planned_only_where_the_layers_split(native_lib, nets):
+    """Overlapping receptive fields (a node of the layer below feeds two nodes above) leave no independent sub-trees: no plan."""
+    for nodes in (helpers.overlapping_net(5), helpers.linear_net(3), nets("T5L-16")):
+        f = Flow(nodes, output_dtype=np.float32)
+        d = f.describe()
+        x = np.random.default_rng(5).integers(0, 256, (40, nodes[0].input_dim)).astype(np.float32)
+        assert rel_err(f.execute(x), oracle.execute_flow(nodes, x)) <= TOL
+        if "sub-trees in ONE launch" in d:      # (a net whose upper layers do split: the roots must be >= 8)
+            assert int(d.split(" sub-trees in ONE launch")[0].split(" as ")[-1]) >= 8
+        f.close()
 
 
 def test_front_kernel_variants_agree(native_lib, nets, monkeypatch):
