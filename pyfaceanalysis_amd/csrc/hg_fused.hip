@@ -1417,7 +1417,14 @@ public:
                 TailParams TP = tail_params((int)si, cur, n_tiles, y, y_dtype, y_cols, ldy, n);
                 // two tiles per workgroup only for narrow tops on long batches, and only while their doubled LDS image fits
                 const int T = (n_tiles >= 512 && tail_waves(TP) <= 8 && tail_lds_bytes(TP, 2) <= (size_t)160 * 1024) ? 2 : 1;
+#ifdef HIGSFA_DIAG
+                const bool stamped = opt_.stamp_stage == (int)si;
+                if (stamped) tail_stamps_begin(TP, (size_t)((n_tiles + T - 1) / T), st);
+#endif
                 launch_tail(TP, T, st);
+#ifdef HIGSFA_DIAG
+                if (stamped) tail_stamps_report("top-of-hierarchy launch", (int)si, TP.n_stages, (size_t)((n_tiles + T - 1) / T), st);
+#endif
                 if (ev)
                     for (size_t k = si; k <= stages_.size(); ++k) HG_HIP(hipEventRecord(ev[e++], st));   // the first event carries the launch's time
                 HG_HIP(hipGetLastError());
@@ -1425,7 +1432,15 @@ public:
             }
             if ((int)si == sub_begin_ && n_tiles <= opt_.subtree_max_tiles) {
                 // a short batch: these layers as independent sub-trees in one launch (hg_fused_tail.hip)
-                launch_subtree(subtree_params(cur, nxt, n_tiles), st);
+                TailParams TP = subtree_params(cur, nxt, n_tiles);
+#ifdef HIGSFA_DIAG
+                const bool stamped = opt_.stamp_stage == (int)si;
+                if (stamped) tail_stamps_begin(TP, (size_t)sub_n_ * n_tiles, st);
+#endif
+                launch_subtree(TP, st);
+#ifdef HIGSFA_DIAG
+                if (stamped) tail_stamps_report("sub-tree launch", (int)si, TP.n_stages, (size_t)sub_n_ * n_tiles, st);
+#endif
                 std::swap(cur, nxt);
                 if (ev)
                     for (int k = 0; k < sub_len_; ++k) HG_HIP(hipEventRecord(ev[e++], st));   // the first event carries the launch's time
@@ -2628,6 +2643,41 @@ private:
             return;
         }
     }
+
+#ifdef HIGSFA_DIAG
+    // k_tail / k_subtree with wall-clock stamps (hg_fused_tail.hip: TAIL_STAMP): where a wave's time goes, layer by layer
+    void tail_stamps_begin(TailParams& TP, size_t blocks, hipStream_t st) {
+        stamp_buf_.alloc(blocks * 16 * 16 * 8);
+        HG_HIP(hipMemsetAsync(stamp_buf_.p, 0, stamp_buf_.bytes, st));
+        TP.stamps = (unsigned long long*)stamp_buf_.p;
+    }
+    void tail_stamps_report(const char* what, int si, int n_layers, size_t blocks, hipStream_t st) {
+        HG_HIP(hipStreamSynchronize(st));
+        std::vector<unsigned long long> h(blocks * 16 * 16);
+        HG_HIP(hipMemcpy(h.data(), stamp_buf_.p, h.size() * 8, hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ull;
+        for (size_t i = 0; i < h.size(); i += 16)
+            if (h[i]) t0 = std::min(t0, h[i]);
+        static const char* names[5] = {"loads in", "expanded", "barrier 1", "outputs stored", "barrier 2"};
+        double sum[16] = {}, mx[16] = {}, cnt[16] = {};
+        for (size_t i = 0; i < h.size(); i += 16)
+            for (int k = 0; k < 16; ++k)
+                if (h[i + k]) {
+                    const double us = (double)(h[i + k] - t0) * 0.01;
+                    sum[k] += us; cnt[k] += 1; mx[k] = std::max(mx[k], us);
+                }
+        fprintf(stderr, "[stamp stage %d] %s, %zu workgroups: us after the first wave's entry, mean (max) over the waves that took part\n", si, what, blocks);
+        fprintf(stderr, "[stamp stage %d]   entry %.2f (%.2f)\n", si, cnt[0] ? sum[0] / cnt[0] : 0.0, mx[0]);
+        for (int l = 0; l < n_layers; ++l) {
+            fprintf(stderr, "[stamp stage %d]   layer %d:", si, l);
+            for (int k = 0; k < 5; ++k) {
+                const int q = 1 + 5 * l + k;
+                fprintf(stderr, "  %s %.2f (%.2f; %.0f waves)", names[k], cnt[q] ? sum[q] / cnt[q] : 0.0, mx[q], cnt[q]);
+            }
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
 
     static void fill_tail_stage(TailStage& S, HostStage& hs) {
         S.afrag = (const f32x4*)hs.d_afrag.p;

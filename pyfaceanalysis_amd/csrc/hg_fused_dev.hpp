@@ -441,6 +441,7 @@ struct TailParams {
     f32x4* out_frag;
     const int32_t* sub_nodes[kMaxTail];      // per fused layer: [sub-tree][position] -> node of the layer
     int32_t n_sub, nb_out_frag;
+    unsigned long long* stamps;              // diagnostic build only (HIGSFA_STAMP): 16 wall-clock stamps per wave
 };
 size_t tail_lds_bytes(const TailParams& P, int T);
 int tail_waves(const TailParams& P);

@@ -29,13 +29,27 @@ constexpr int KB = 8;      // K-blocks loaded per batch (all of a 120-input node
 
 enum { OUT_LDS = 0, OUT_Y = 1, OUT_FRAG = 2 };
 
+// Diagnostic build (HIGSFA_DIAG, tools/build_diag_lib.sh; HIGSFA_STAMP=<stage> picks the launch): wall-clock stamps (100 MHz) of
+// every wave at the kernel's entry and, per layer, when its loads have arrived, when its expanded tiles are stored, behind the
+// first barrier, when its outputs are stored, behind the second barrier.  The product build compiles none of it.
+#ifdef HIGSFA_DIAG
+#define TAIL_STAMP(i)                                                                                            \
+    do {                                                                                                         \
+        if (P.stamps && lane == 0) P.stamps[((size_t)blockIdx.x * 16 + w) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#define TAIL_LOADS_DONE() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#else
+#define TAIL_STAMP(i)
+#define TAIL_LOADS_DONE()
+#endif
+
 // One layer for this workgroup's T tiles.  FIRST: inputs come from global memory (P.in), else from the LDS buffer `src`.
 // OUT_Y: outputs go to the caller's y; OUT_FRAG: to P.out_frag in fragment order; OUT_LDS: to the LDS buffer `dst` (block-major:
 // block b of tile t at (b * T + t) * 64).  k_subtree: the workgroup's nodes are nmap[0 .. S.n_nodes - 1] of the layer.
 template <int T, bool FIRST, int OUT>
 __device__ __forceinline__ void tail_layer(const TailParams& P, const TailStage& S, const f32x4* src, f32x4* dst, f32x4* ebuf,
                                            const int (&tile)[T], const uint32_t (&trow)[T], int w, int lane,
-                                           const int32_t* nmap = nullptr) {
+                                           const int32_t* nmap = nullptr, int sidx = 0) {
     constexpr bool LAST = OUT == OUT_Y;
     const int g = lane >> 4;
     const int wpn = S.has_exp ? (S.mt1 > S.mt2 ? S.mt1 : S.mt2) : S.mt1;      // waves per node
@@ -120,6 +134,12 @@ __device__ __forceinline__ void tail_layer(const TailParams& P, const TailStage&
                     else bf[k][t] = src[((size_t)sb * T + t) * 64 + lane];
                 }
             }
+#ifdef HIGSFA_DIAG
+            if (k0 == 0) {
+                TAIL_LOADS_DONE();
+                TAIL_STAMP(1 + 5 * sidx);
+            }
+#endif
 #pragma unroll
             for (int k = 0; k < KB; ++k) {
                 const int nk = nks[k] & 255, r0 = nks[k] >> 8;      // (r0 > 0: a packed remainder block of the layer below)
@@ -149,7 +169,9 @@ __device__ __forceinline__ void tail_layer(const TailParams& P, const TailStage&
             }
         }
     }
+    TAIL_STAMP(2 + 5 * sidx);
     __syncthreads();                 // expanded tiles of every node are in LDS (a linear layer passes straight through)
+    TAIL_STAMP(3 + 5 * sidx);
     if (g2) {
         f32x4 y[T];
         const f32x4 bb = *(const f32x4*)(bnode + (mt1n + mw) * 16);
@@ -179,7 +201,9 @@ __device__ __forceinline__ void tail_layer(const TailParams& P, const TailStage&
         }
         emit(y);
     }
+    TAIL_STAMP(4 + 5 * sidx);
     if constexpr (OUT == OUT_LDS) __syncthreads();      // this layer's output tiles are in LDS; ebuf is free again
+    TAIL_STAMP(5 + 5 * sidx);
 }
 
 template <int T, int WAVES>
@@ -187,6 +211,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_tail(TailParams P) {
     extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    TAIL_STAMP(0);
     int tile[T];
     uint32_t trow[T];
 #pragma unroll
@@ -198,14 +223,14 @@ __global__ void __launch_bounds__(WAVES * 64) k_tail(TailParams P) {
     f32x4* act1 = smem + (size_t)P.act_blocks * T * 64;
     f32x4* ebuf = act1 + (size_t)P.act_blocks * T * 64;
     if (P.n_stages == 1) {
-        tail_layer<T, true, OUT_Y>(P, P.st[0], nullptr, nullptr, ebuf, tile, trow, w, lane);
+        tail_layer<T, true, OUT_Y>(P, P.st[0], nullptr, nullptr, ebuf, tile, trow, w, lane, nullptr, 0);
     } else if (P.n_stages == 2) {
-        tail_layer<T, true, OUT_LDS>(P, P.st[0], nullptr, act0, ebuf, tile, trow, w, lane);
-        tail_layer<T, false, OUT_Y>(P, P.st[1], act0, nullptr, ebuf, tile, trow, w, lane);
+        tail_layer<T, true, OUT_LDS>(P, P.st[0], nullptr, act0, ebuf, tile, trow, w, lane, nullptr, 0);
+        tail_layer<T, false, OUT_Y>(P, P.st[1], act0, nullptr, ebuf, tile, trow, w, lane, nullptr, 1);
     } else {
-        tail_layer<T, true, OUT_LDS>(P, P.st[0], nullptr, act0, ebuf, tile, trow, w, lane);
-        tail_layer<T, false, OUT_LDS>(P, P.st[1], act0, act1, ebuf, tile, trow, w, lane);
-        tail_layer<T, false, OUT_Y>(P, P.st[2], act1, nullptr, ebuf, tile, trow, w, lane);
+        tail_layer<T, true, OUT_LDS>(P, P.st[0], nullptr, act0, ebuf, tile, trow, w, lane, nullptr, 0);
+        tail_layer<T, false, OUT_LDS>(P, P.st[1], act0, act1, ebuf, tile, trow, w, lane, nullptr, 1);
+        tail_layer<T, false, OUT_Y>(P, P.st[2], act1, nullptr, ebuf, tile, trow, w, lane, nullptr, 2);
     }
 }
 
@@ -220,6 +245,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_subtree(TailParams P) {
     extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    TAIL_STAMP(0);
     const int sub = blockIdx.x % P.n_sub, tb = blockIdx.x / P.n_sub;
     int tile[T];
     uint32_t trow[T];
@@ -234,13 +260,13 @@ __global__ void __launch_bounds__(WAVES * 64) k_subtree(TailParams P) {
     const int32_t* m0 = P.sub_nodes[0] + sub * P.st[0].n_nodes;
     const int32_t* m1 = P.sub_nodes[1] + sub * P.st[1].n_nodes;
     if (P.n_stages == 2) {
-        tail_layer<T, true, OUT_LDS>(P, P.st[0], nullptr, act0, ebuf, tile, trow, w, lane, m0);
-        tail_layer<T, false, OUT_FRAG>(P, P.st[1], act0, nullptr, ebuf, tile, trow, w, lane, m1);
+        tail_layer<T, true, OUT_LDS>(P, P.st[0], nullptr, act0, ebuf, tile, trow, w, lane, m0, 0);
+        tail_layer<T, false, OUT_FRAG>(P, P.st[1], act0, nullptr, ebuf, tile, trow, w, lane, m1, 1);
     } else {
         const int32_t* m2 = P.sub_nodes[2] + sub * P.st[2].n_nodes;
-        tail_layer<T, true, OUT_LDS>(P, P.st[0], nullptr, act0, ebuf, tile, trow, w, lane, m0);
-        tail_layer<T, false, OUT_LDS>(P, P.st[1], act0, act1, ebuf, tile, trow, w, lane, m1);
-        tail_layer<T, false, OUT_FRAG>(P, P.st[2], act1, nullptr, ebuf, tile, trow, w, lane, m2);
+        tail_layer<T, true, OUT_LDS>(P, P.st[0], nullptr, act0, ebuf, tile, trow, w, lane, m0, 0);
+        tail_layer<T, false, OUT_LDS>(P, P.st[1], act0, act1, ebuf, tile, trow, w, lane, m1, 1);
+        tail_layer<T, false, OUT_FRAG>(P, P.st[2], act1, nullptr, ebuf, tile, trow, w, lane, m2, 2);
     }
 }
 
