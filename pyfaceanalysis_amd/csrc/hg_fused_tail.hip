@@ -102,6 +102,8 @@ __device__ __forceinline__ void tail_layer(const TailParams& P, const TailStage&
     const bool g1 = on && mw < mt1n && (S.has_exp || need_out);
     const bool g2 = on && S.has_exp && mw < mt2n && need_out;
     // GEMM-2 weights of this wave's output tile do not depend on z: fetch them first
+    // (measured late in round 5: requesting them BEHIND the first GEMM's blocks, so that the first MFMA does not wait for their 8 KiB
+    // per wave as well, costs 2 us per short call — profiles/r05_tail_warm.txt)
     f32x4 a2[KB];
     const int k2n = mt1n * nf;
     if (g2) {
