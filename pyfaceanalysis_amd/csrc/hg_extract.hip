@@ -124,6 +124,85 @@ __global__ void __launch_bounds__(256) k_extent_gather(const FT* __restrict__ fr
     }
 }
 
+// uint8 frame -> uint8 windows whose rows are a multiple of 16 pixels (the cascade's first stage: 1738 windows of 128 x 128 from a
+// 1000 x 562 frame, 28 MB of output).  k_extent_gather above issues, per four pixels, one table load, four byte loads and one
+// 4-byte store: 24 memory instructions per 16 pixels, and it is their issue that bounds it (35 us = 0.8 TB/s written).  Here a
+// thread owns sixteen output columns of its window for all the rows of its workgroup: the column indices are read once and kept in
+// registers; a window at most twice as wide as its output (most of a pyramid: the number of windows falls with the square of
+// their size) has the four source pixels of four output pixels inside eight consecutive bytes, so ONE unaligned 8-byte load
+// (gfx950 runs in unaligned-access mode: the compiler itself emits global_load_dwordx2 for a byte-aligned 8-byte copy) replaces
+// four byte loads; one 16-byte store per row.  5 memory instructions per 16 pixels.  Same bytes: every pixel is still
+// frame[ytab[y]][xtab[x]] or 0.
+__global__ void __launch_bounds__(256) k_extent_gather_u8x16(const uint8_t* __restrict__ frame, int64_t ld, int fw, const int32_t* __restrict__ tabs,
+                                                             int64_t n, int w, int h, uint8_t* __restrict__ out, int64_t ldo, int rows_per_wg) {
+    const int tpr = w >> 4;                                   // threads per output row (a power of two, <= 256)
+    const int tx = threadIdx.x & (tpr - 1), ty = threadIdx.x / tpr, rows_per_pass = 256 / tpr;
+    const int y_begin = blockIdx.x * rows_per_wg, y_end = min(h, y_begin + rows_per_wg);
+    for (int64_t b = blockIdx.y; b < n; b += gridDim.y) {
+        const int32_t* t = tabs + b * (w + h);
+        int xs[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int4 v = *(const int4*)(t + tx * 16 + q * 4);      // (table rows are 16-byte aligned: checked by the launcher)
+            xs[q * 4] = v.x; xs[q * 4 + 1] = v.y; xs[q * 4 + 2] = v.z; xs[q * 4 + 3] = v.w;
+        }
+        // a group of four columns can come out of one 8-byte load if all four are inside the frame, ascending within 8 bytes of the
+        // first, and the 8 bytes end inside the frame's row.  The choice is made per WAVE and the loads carry no per-lane branch
+        // (a branch per load puts a wait behind each one: the loads of a row, and of the four rows of the unrolled loop, must overlap)
+        bool all8 = true;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int x0 = xs[g * 4];
+            bool asc = x0 >= 0;
+#pragma unroll
+            for (int k = 1; k < 4; ++k) asc = asc && xs[g * 4 + k] >= x0;
+            all8 = all8 && asc && xs[g * 4 + 3] < x0 + 8 && xs[g * 4 + 2] < x0 + 8 && xs[g * 4 + 1] < x0 + 8 && x0 + 8 <= fw;
+        }
+        const bool wave8 = __builtin_amdgcn_ballot_w64(!all8) == 0;
+        uint8_t* dst = out + b * ldo + tx * 16;
+        if (wave8) {
+#pragma unroll 4
+            for (int y = y_begin + ty; y < y_end; y += rows_per_pass) {      // (unrolled: the rows' loads overlap, one latency for four rows)
+                const int ys = t[w + y];
+                const uint8_t* src = frame + (int64_t)(ys >= 0 ? ys : 0) * ld;
+                uint32_t pk[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint64_t c;
+                    __builtin_memcpy(&c, src + xs[g * 4], 8);
+                    uint32_t v = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v |= (uint32_t)((c >> (8 * (xs[g * 4 + k] - xs[g * 4]))) & 0xffull) << (8 * k);
+                    pk[g] = ys >= 0 ? v : 0u;
+                }
+                *(uint4*)(dst + (int64_t)y * w) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            }
+        } else {
+            // wide windows, windows that leave the frame: a byte load per pixel from a clamped address, the value masked afterwards
+            // (a middle tier — one 16-byte load per four pixels for windows up to four times as wide as their output — was measured:
+            // 23.7 us against 20.2 for the first stage's 1738 windows; the third code path costs registers every wave pays for)
+#pragma unroll 2
+            for (int y = y_begin + ty; y < y_end; y += rows_per_pass) {
+                const int ys = t[w + y];
+                const uint8_t* src = frame + (int64_t)(ys >= 0 ? ys : 0) * ld;
+                uint32_t pk[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint32_t v = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int x = xs[g * 4 + k];
+                        const uint32_t px = src[x >= 0 ? x : 0];
+                        v |= ((x >= 0 && ys >= 0) ? px : 0u) << (8 * k);
+                    }
+                    pk[g] = v;
+                }
+                *(uint4*)(dst + (int64_t)y * w) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            }
+        }
+    }
+}
+
 // Per-box rotation record (Image.rotate's matrix as affine_fixed / ImagingScaleAffine use it).
 struct RotCoef {
     int32_t mode;            // 0: no rotation, 1: fixed point, 2: scaling branch (sin rounds to 0), 3: outside the fixed-point range
@@ -293,8 +372,23 @@ int guarded(F&& fn) {
 }
 
 template <typename FT>
-void launch_gather(const void* frame, int64_t ld, const int32_t* tabs, int64_t n, int w, int h, void* out, int out_dtype, int64_t ldo,
+void launch_gather(const void* frame, int64_t ld, int fw, const int32_t* tabs, int64_t n, int w, int h, void* out, int out_dtype, int64_t ldo,
                    hipStream_t st) {
+    if constexpr (sizeof(FT) == 1) {
+        const int tpr = w >> 4;
+        static const bool v1 = getenv("HIGSFA_EXTENT_V1") != nullptr;      // (A/B: the four-pixels-per-thread kernel for every shape)
+        if (!v1 && out_dtype == HG_U8 && (w & 15) == 0 && tpr >= 1 && tpr <= 256 && (tpr & (tpr - 1)) == 0 && ((w + h) & 3) == 0 && (ldo & 15) == 0 &&
+            ((uintptr_t)out & 15) == 0 && ((uintptr_t)tabs & 15) == 0) {
+            // whole windows per workgroup while that leaves >= 1024 workgroups, else row chunks (the column indices are read once per chunk)
+            const int rows_per_pass = 256 / tpr;
+            int passes = (h + rows_per_pass - 1) / rows_per_pass;
+            while (passes > 1 && n * ((h + rows_per_pass * passes - 1) / (rows_per_pass * passes)) < 1024) passes = (passes + 1) / 2;
+            const int rows_per_wg = rows_per_pass * passes;
+            const dim3 grid((unsigned)((h + rows_per_wg - 1) / rows_per_wg), (unsigned)std::min<int64_t>(n, 65535));
+            hipLaunchKernelGGL(k_extent_gather_u8x16, grid, 256, 0, st, (const uint8_t*)frame, ld, fw, tabs, n, w, h, (uint8_t*)out, ldo, rows_per_wg);
+            return;
+        }
+    }
     const unsigned tx = w >= 1024 ? 256 : w >= 256 ? 64 : 32;       // four pixels per thread on the uint8 path
     const dim3 thr(tx, 256 / tx);
     const dim3 grid((unsigned)((h + thr.y - 1) / thr.y), (unsigned)std::min<int64_t>(n, 65535));
@@ -381,9 +475,9 @@ int hg_patcher_extract_rotate_device(hg_patcher* p, const void* frame_dev, int f
                 launch_gather_rot<float>(frame_dev, ld, frame_w, frame_h, (const int32_t*)p->tabs.p, (const RotCoef*)p->rot.p, n, out_w, out_h, out_dev,
                                          out_dtype, ldo, st);
         } else if (frame_dtype == HG_U8) {
-            launch_gather<uint8_t>(frame_dev, ld, (const int32_t*)p->tabs.p, n, out_w, out_h, out_dev, out_dtype, ldo, st);
+            launch_gather<uint8_t>(frame_dev, ld, frame_w, (const int32_t*)p->tabs.p, n, out_w, out_h, out_dev, out_dtype, ldo, st);
         } else {
-            launch_gather<float>(frame_dev, ld, (const int32_t*)p->tabs.p, n, out_w, out_h, out_dev, out_dtype, ldo, st);
+            launch_gather<float>(frame_dev, ld, frame_w, (const int32_t*)p->tabs.p, n, out_w, out_h, out_dev, out_dtype, ldo, st);
         }
         HG_HIP(hipGetLastError());
     });
@@ -411,8 +505,8 @@ int hg_patcher_extract_keyed_device(hg_patcher* p, uint64_t key, const void* fra
             hipLaunchKernelGGL(k_extent_tables, (unsigned)((n_ent + 255) / 256), 256, 0, st, boxes_dev, n, out_w, out_h, frame_w, frame_h, (int32_t*)K->tabs.p,
                                (const double*)nullptr, (RotCoef*)nullptr);
         }
-        if (frame_dtype == HG_U8) launch_gather<uint8_t>(frame_dev, ld, (const int32_t*)K->tabs.p, n, out_w, out_h, out_dev, out_dtype, ldo, st);
-        else launch_gather<float>(frame_dev, ld, (const int32_t*)K->tabs.p, n, out_w, out_h, out_dev, out_dtype, ldo, st);
+        if (frame_dtype == HG_U8) launch_gather<uint8_t>(frame_dev, ld, frame_w, (const int32_t*)K->tabs.p, n, out_w, out_h, out_dev, out_dtype, ldo, st);
+        else launch_gather<float>(frame_dev, ld, frame_w, (const int32_t*)K->tabs.p, n, out_w, out_h, out_dev, out_dtype, ldo, st);
         HG_HIP(hipGetLastError());
     });
 }

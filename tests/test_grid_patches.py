@@ -37,9 +37,14 @@ def test_patch_extraction_matches_pil(native_lib):
     frame = rng.integers(0, 256, (562, 1000), dtype=np.uint8)
     im = Image.fromarray(frame, "L")
     p = Patcher()
-    for size in ((64, 64), (128, 128), (37, 21)):
+    # (uint8 windows whose rows are a multiple of 16 pixels take the sixteen-pixels-per-thread kernel — 8-byte loads where four source
+    # pixels lie within eight bytes, byte loads where they do not: windows narrower and wider than their output, at the frame's right
+    # edge, partly outside; (48, 5), (37, 21): the four-pixels-per-thread kernel)
+    for size in ((64, 64), (128, 128), (37, 21), (16, 16), (256, 32), (128, 100), (48, 5)):
         boxes = np.concatenate([b for _, b in grid.frame_boxes(1000, 562, 0.2, subimage_size=(64, 64))])[::3]
-        extra = np.array([[-5.5, -3.25, 40.0, 30.0], [950.0, 520.0, 1020.5, 580.0], [10.0, 10.0, 11.0, 11.0]])   # partly outside
+        extra = np.array([[-5.5, -3.25, 40.0, 30.0], [950.0, 520.0, 1020.5, 580.0], [10.0, 10.0, 11.0, 11.0],   # partly outside / tiny
+                          [0.0, 0.0, 999.0, 561.0], [960.0, 500.0, 999.0, 561.0], [990.0, 3.0, 999.9, 9.0], [100.25, 50.5, 163.75, 120.0],
+                          [3.0, 3.0, 950.0, 40.0]])
         boxes = np.vstack([boxes, extra])
         ref = np.stack([np.asarray(im.transform(size, Image.EXTENT, tuple(b), Image.NEAREST)).reshape(-1) for b in boxes])
         for dt in (np.uint8, np.float32, np.float64):
