@@ -300,28 +300,47 @@ __device__ __forceinline__ void gather_rot_row(const FT* __restrict__ frame, int
             // addresses first, then sixteen independent loads in flight and ONE 16-byte store — a thread with four pixels spent
             // its time in three dependent round trips (table -> frame -> store): 51 us for the first stage's 1738 windows
             if ((w & 15) == 0 && (((uintptr_t)dst) & 15) == 0 && rc.mode != 2) {
+                // (round 5: no branch between the loads — the sixteen table entries as four 16-byte loads where the table row allows it,
+                // the rotation mode tested once per box, every pixel load unconditional from a clamped address and masked afterwards;
+                // with a branch around each load the compiler put a wait behind each one)
+                const bool tab16 = ((uintptr_t)t & 15) == 0;
+                const int mode = rc.mode;
                 for (int x = tx * 16; x < w; x += ntx * 16) {
-                    int64_t off[16];
+                    int xr[16];
+                    if (tab16) {
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const int xr = t[x + q];
-                        int xs = xr, ys = yr;
-                        if (rc.mode == 1) {
-                            const int64_t xx = (int64_t)rc.A[2] + (int64_t)yr * rc.A[1] + (int64_t)xr * rc.A[0];
-                            const int64_t yy = (int64_t)rc.A[5] + (int64_t)yr * rc.A[4] + (int64_t)xr * rc.A[3];
-                            xs = (int)(xx >> 16); ys = (int)(yy >> 16);
-                        } else if (rc.mode == 3) {
-                            xs = ys = -1;      // outside the fixed-point range: the window stays 0
+                        for (int q = 0; q < 4; ++q) {
+                            const int4 v = *(const int4*)(t + x + q * 4);
+                            xr[q * 4] = v.x; xr[q * 4 + 1] = v.y; xr[q * 4 + 2] = v.z; xr[q * 4 + 3] = v.w;
                         }
-                        const bool in = xr >= 0 && yr >= 0 && xs >= 0 && xs < fw && ys >= 0 && ys < fh;
-                        off[q] = in ? (int64_t)ys * ld + xs : -1;
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) xr[q] = t[x + q];
                     }
+                    int64_t off[16];
+                    bool in[16];
+                    if (mode == 1) {
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) {
+                            const int64_t xx = (int64_t)rc.A[2] + (int64_t)yr * rc.A[1] + (int64_t)xr[q] * rc.A[0];
+                            const int64_t yy = (int64_t)rc.A[5] + (int64_t)yr * rc.A[4] + (int64_t)xr[q] * rc.A[3];
+                            const int xs = (int)(xx >> 16), ys = (int)(yy >> 16);
+                            in[q] = (xr[q] >= 0) & (yr >= 0) & (xs >= 0) & (xs < fw) & (ys >= 0) & (ys < fh);      // (&: no short-circuit branches)
+                            off[q] = in[q] ? (int64_t)ys * ld + xs : 0;
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) {
+                            in[q] = (mode == 0) & (xr[q] >= 0) & (yr >= 0) & (xr[q] < fw) & (yr < fh);      // (mode 3: outside the fixed-point range, the window stays 0)
+                            off[q] = in[q] ? (int64_t)yr * ld + xr[q] : 0;
+                        }
+                    }
+                    uint32_t px[16];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) px[q] = (uint32_t)(uint8_t)frame[off[q]];
                     uint32_t pk[4] = {0, 0, 0, 0};
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const uint32_t v = off[q] >= 0 ? (uint32_t)(uint8_t)frame[off[q]] : 0u;
-                        pk[q >> 2] |= v << (8 * (q & 3));
-                    }
+                    for (int q = 0; q < 16; ++q) pk[q >> 2] |= (in[q] ? px[q] : 0u) << (8 * (q & 3));
                     *(uint4*)(dst + x) = uint4{pk[0], pk[1], pk[2], pk[3]};
                 }
                 return;
