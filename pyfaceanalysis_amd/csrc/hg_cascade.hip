@@ -280,6 +280,9 @@ struct GroupDesc {
 };
 
 // candidate i through the group's stages; returns whether it survives all of them, alive_after bit s = alive after stage s
+// (requesting the regression values of ALL the group's stages and the original window's nine numbers up front, so that the loads
+// overlap, was measured late in round 5: k_cascade_group 62.8 -> 70.1 us per frame — most candidates die at the group's first stage
+// and never needed them.  Not kept.)
 __device__ __forceinline__ bool group_one(const GroupDesc& G, const hg_cascade_consts& c0, const StageArrays& A, int64_t reg_stride, int i, double& x0,
                                           double& y0, double& x1, double& y1, double& ang, double& cf, int32_t oi, unsigned& alive_after) {
     bool alive = true;
