@@ -51,7 +51,8 @@ struct FusedOptions {
     bool no_direct = false;       // HIGSFA_NO_DIRECT: front kernel always stages the input rows through LDS (k_stage01p)
     int tail_max = 3;             // HIGSFA_TAIL: most layers k_tail fuses at the top of the hierarchy (0: off — per-layer launches + k_unpack)
     bool no_fspec = false;        // HIGSFA_NO_FSPEC: front kernel without the compile-time (identity, abs-power) expansion
-    int subtree_max_tiles = 32;   // HIGSFA_SUBTREE: batches of up to this many 16-row tiles run the layers below the top as sub-trees (k_subtree); 0: never
+    int subtree_max_tiles = 64;   // HIGSFA_SUBTREE: batches of up to this many 16-row tiles may run layers below the top as sub-trees (k_subtree); 0: never
+    int subtree_max_wgs = 256;    // HIGSFA_SUBTREE_WGS: ... while sub-trees x tiles stays within this many workgroups
     int splitm_max_nodes = 4;     // experiments: HIGSFA_SPLITM_MAX
     int splitm_max_wgs = 512;     // HIGSFA_SPLITM_WGS: largest k_stage_splitm grid for layers of more than splitm_max_nodes nodes
     int shape_variant = 0;        // experiments: HIGSFA_SHAPES
@@ -74,6 +75,7 @@ struct FusedOptions {
         if (const char* e = getenv("HIGSFA_SPLITM_WGS")) o.splitm_max_wgs = atoi(e);
         if (const char* e = getenv("HIGSFA_SHAPES")) o.shape_variant = atoi(e);
         if (const char* e = getenv("HIGSFA_SUBTREE")) o.subtree_max_tiles = std::max(0, atoi(e));
+        if (const char* e = getenv("HIGSFA_SUBTREE_WGS")) o.subtree_max_wgs = std::max(0, atoi(e));
         if (const char* e = getenv("HIGSFA_TAIL")) o.tail_max = std::max(0, std::min(atoi(e), kMaxTail));
         return o;
     }
@@ -953,6 +955,11 @@ inline int q_of_row(int i) { return 4 * (i & 3) + (i >> 2); }  // tile row -> ti
 constexpr int kStage0ChunkCols = 128;   // columns of one sub-image staged per chunk (T = 4 tiles -> ~66 KiB LDS)
 constexpr int kWeightLdsKiB = 64;       // target size of a node group's weights in LDS
 
+// layers [begin, begin + len) as n independent sub-trees in one launch (k_subtree, short batches; plan_subtree)
+struct SubRun {
+    int begin = 0, len = 0, n = 0, act_blocks = 0, e_blocks = 0;
+};
+
 struct HostStage {
     int mt1 = 1, mt2 = 1, mto = 1, nb_out = 0, nb_in = 0, n_nodes = 0, kb1 = 0, nf = 0;
     int node_blocks = 0, bias_floats = 0, nk_last = 4;
@@ -1430,16 +1437,20 @@ public:
                 HG_HIP(hipGetLastError());
                 return;
             }
-            if ((int)si == sub_begin_ && n_tiles <= opt_.subtree_max_tiles) {
+            const SubRun* sr = nullptr;
+            for (const SubRun& r : sub_runs_)
+                if (r.begin == (int)si && sub_run_pays(r, n_tiles)) sr = &r;
+            if (sr) {
                 // a short batch: these layers as independent sub-trees in one launch (hg_fused_tail.hip)
-                TailParams TP = subtree_params(cur, nxt, n_tiles);
+                const int sub_len_ = sr->len;
+                TailParams TP = subtree_params(*sr, cur, nxt, n_tiles);
 #ifdef HIGSFA_DIAG
                 const bool stamped = opt_.stamp_stage == (int)si;
-                if (stamped) tail_stamps_begin(TP, (size_t)sub_n_ * n_tiles, st);
+                if (stamped) tail_stamps_begin(TP, (size_t)sr->n * n_tiles, st);
 #endif
                 launch_subtree(TP, st);
 #ifdef HIGSFA_DIAG
-                if (stamped) tail_stamps_report("sub-tree launch", (int)si, TP.n_stages, (size_t)sub_n_ * n_tiles, st);
+                if (stamped) tail_stamps_report("sub-tree launch", (int)si, TP.n_stages, (size_t)sr->n * n_tiles, st);
 #endif
                 std::swap(cur, nxt);
                 if (ev)
@@ -2561,21 +2572,23 @@ private:
                                       : "  [in the top-of-hierarchy launch]";
     }
 
-    // Layers below the top that fall into independent sub-trees (k_subtree, hg_fused_tail.hip): the run of up to three ordinary
-    // layers that ends just below the top-of-hierarchy launch of a short batch, if the nodes each root (node of the run's last
-    // layer) draws on, layer by layer, are as many for every root and shared with no other root.
+    // Layers below the top that fall into independent sub-trees (k_subtree, hg_fused_tail.hip): runs of two or three ordinary
+    // layers under the top-of-hierarchy launch of a short batch, if the nodes each root (node of a run's last layer) draws on,
+    // layer by layer, are as many for every root and shared with no other root.
     void plan_subtree() {
-        sub_begin_ = -1;
+        sub_runs_.clear();
         if (opt_.subtree_max_tiles <= 0) return;
         const int ns = (int)stages_.size();
         // (the layer under a short batch's k_tail launch runs alone: tail_start)
-        const int end = tail_begin_ < 0 ? ns : (ns - tail_begin_ >= 3 ? tail_begin_ + 1 : tail_begin_) - 1;
-        for (int last = end - 1; last >= 2; --last) {
+        int end = tail_begin_ < 0 ? ns : (ns - tail_begin_ >= 3 ? tail_begin_ + 1 : tail_begin_);
+        // runs are taken from the top down, each ending where the one above begins (U11L: layers 6-8 as 4 sub-trees of 4 + 2 + 1 nodes, then
+        // layers 4-5 as 32 sub-trees of 2 + 1; the layers below pack their remainder tiles and stay per-layer launches)
+        while (end - 1 >= 2) {
+            const int last = end - 1;
             const int k = stages_[last].n_nodes;
-            if (k < 8) continue;      // fewer workgroups per tile than XCDs: per-layer launches keep more of the chip busy
             int b = last + 1, act_blocks = 0, e_blocks = 0;
             std::vector<std::vector<int32_t>> members(kMaxTail), tabs(kMaxTail);      // by distance from `last`
-            while (b > (fuse01_ ? 2 : 1) && last + 1 - b < kMaxTail) {
+            while (k >= 4 && b > (fuse01_ ? 2 : 1) && last + 1 - b < kMaxTail) {
                 const HostStage& s = stages_[b - 1];
                 if (s.kind != 0 || s.from_x || s.rem4 || s.pack_out || s.nf > kMaxFuncs || s.n_nodes % k) break;
                 if (s.has_exp && s.mt1 * s.nf > 8) break;
@@ -2627,20 +2640,25 @@ private:
                 if (b - 1 < last) tabs[last - b] = std::move(tab);      // the table of the layer above this one
                 --b;
             }
-            if (last + 1 - b < 2) continue;
-            sub_begin_ = b;
-            sub_len_ = last + 1 - b;
-            sub_n_ = k;
-            sub_act_blocks_ = act_blocks;
-            sub_e_blocks_ = e_blocks;
+            if (last + 1 - b < 2) {      // no run ends here: this layer stays a launch of its own
+                end = last;
+                continue;
+            }
+            SubRun r;
+            r.begin = b;
+            r.len = last + 1 - b;
+            r.n = k;
+            r.act_blocks = act_blocks;
+            r.e_blocks = e_blocks;
+            sub_runs_.push_back(r);
             for (int i = b; i <= last; ++i) {
                 stages_[i].sub_nodes = members[last - i];
                 if (i > b) stages_[i].sub_kb1tab = tabs[last - i];
-                stages_[i].name += i == b ? "  [batches of up to " + std::to_string(opt_.subtree_max_tiles * 16) + " rows: this and the next " +
-                                                std::to_string(sub_len_ - 1) + " layer(s) as " + std::to_string(k) + " sub-trees in ONE launch]"
+                stages_[i].name += i == b ? "  [batches of up to " + std::to_string(std::min(opt_.subtree_max_tiles, opt_.subtree_max_wgs / k) * 16) + " rows: this and the next " +
+                                                std::to_string(r.len - 1) + " layer(s) as " + std::to_string(k) + " sub-trees in ONE launch]"
                                           : "  [in the sub-tree launch for short batches]";
             }
-            return;
+            end = b;
         }
     }
 
@@ -2700,7 +2718,8 @@ private:
         }
     }
 
-    TailParams subtree_params(const f32x4* in, f32x4* out, int n_tiles) {
+    TailParams subtree_params(const SubRun& sr, const f32x4* in, f32x4* out, int n_tiles) {
+        const int sub_begin_ = sr.begin, sub_len_ = sr.len, sub_n_ = sr.n, sub_act_blocks_ = sr.act_blocks, sub_e_blocks_ = sr.e_blocks;
         TailParams TP{};
         TP.n_stages = sub_len_;
         for (int k = 0; k < sub_len_; ++k) {
@@ -2724,9 +2743,19 @@ private:
     // Three fused layers pay off from ~1400 rows on (call times against N, profiles/r03_call_times.txt: 16 waves per workgroup walk
     // the three layers' latencies one after the other — 23 us however small the batch, against 6 us for a k_stage_splitm launch of
     // the 4-node layer plus 13 us for the two layers above it); below that the launch starts one layer later.  Same bits either way.
+    // A sub-tree launch pays while all its workgroups (sub-trees x batch tiles, each pulling its sub-tree's weights through ONE compute
+    // unit's L1) are resident at once, one per CU: measured on U11L-128 (profiles/r05_subtree_call_times.txt) 8 sub-trees gain up to 512
+    // rows = 256 workgroups and lose from 728; 32 sub-trees gain up to 44 rows and lose from 130.
+    bool sub_run_pays(const SubRun& r, int n_tiles) const {
+        return n_tiles <= opt_.subtree_max_tiles && (int64_t)r.n * n_tiles <= opt_.subtree_max_wgs;
+    }
+
     int tail_start(int n_tiles) const {
         const int ns = (int)stages_.size();
-        return (ns - tail_begin_ >= 3 && n_tiles < 96) ? tail_begin_ + 1 : tail_begin_;
+        bool short_batch = n_tiles < 96;
+        for (const SubRun& r : sub_runs_)      // (a sub-tree run that takes the top launch's first layer: only with HIGSFA_SUBTREE_WGS raised)
+            if (r.begin <= tail_begin_ && tail_begin_ < r.begin + r.len && sub_run_pays(r, n_tiles)) short_batch = true;
+        return (ns - tail_begin_ >= 3 && short_batch) ? tail_begin_ + 1 : tail_begin_;
     }
 
     TailParams tail_params(int begin, const f32x4* in, int n_tiles, void* y, int y_dtype, int64_t y_cols, int64_t ldy, int64_t n) {
@@ -2780,7 +2809,7 @@ private:
     DevBuf d_col_base_, d_col_of_, bufA_, bufB_, stamp_buf_;
     int tail_begin_ = -1;         // first stage of the top-of-hierarchy launch (k_tail); -1: none
     int tail_act_blocks_ = 0, tail_e_blocks_ = 0;
-    int sub_begin_ = -1, sub_len_ = 0, sub_n_ = 0, sub_act_blocks_ = 0, sub_e_blocks_ = 0;      // k_subtree run (short batches); -1: none
+    std::vector<SubRun> sub_runs_;      // k_subtree runs (short batches)
     WorkQueue wq_front_, wq_direct_, wq_direct_wg_;
     int32_t* err_host_ = nullptr;
     int32_t* err_dev_ = nullptr;
