@@ -84,8 +84,8 @@ def test_host_path_soak_five_seconds(native_lib):
     assert bad == 0 and calls > 500
 
 
-def test_wide_fuzz_fifty_hierarchies(native_lib):
-    bad, tails, n = [], 0, 0
+def test_wide_fuzz_fifty_hierarchies(native_lib, monkeypatch):
+    bad, tails, subs, n = [], 0, 0, 0
     for kind, maker, seeds in (("net", helpers.fuzz_net, range(100, 130)), ("prod", helpers.fuzz_product_net, range(100, 112)),
                                ("igsfa", helpers.fuzz_igsfa_net, range(100, 108))):
         for seed in seeds:
@@ -95,6 +95,15 @@ def test_wide_fuzz_fifty_hierarchies(native_lib):
             f = Flow(nodes)
             tails += "no unpack pass" in f.describe()
             y = f.execute(x)
+            if "sub-trees in ONE launch" in f.describe():      # layers run as sub-trees for these few rows: same bits as per-layer launches
+                subs += 1
+                monkeypatch.setenv("HIGSFA_SUBTREE", "0")
+                g = Flow(nodes)
+                same = "sub-trees in ONE launch" not in g.describe() and np.array_equal(g.execute(x), y)
+                monkeypatch.delenv("HIGSFA_SUBTREE")
+                g.close()
+                if not same:
+                    bad.append((kind, seed, "sub-tree launch differs", f.info().plan_kind))
             k = int(rng.integers(1, nodes[-1].output_dim + 1))
             yk = f.execute(x, n_cols=k)
             ref = oracle.execute_flow(nodes, x)
@@ -103,5 +112,5 @@ def test_wide_fuzz_fifty_hierarchies(native_lib):
                 bad.append((kind, seed, float(err), f.info().plan_kind))
             n += 1
             f.close()
-    print("wide fuzz: %d flows, %d with the top-of-hierarchy launch, mismatches: %r" % (n, tails, bad))
+    print("wide fuzz: %d flows, %d with the top-of-hierarchy launch, %d with sub-tree launches, mismatches: %r" % (n, tails, subs, bad))
     assert n == 50 and not bad
