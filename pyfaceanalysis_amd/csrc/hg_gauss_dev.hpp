@@ -49,6 +49,8 @@ __device__ __forceinline__ void gauss_rows_wg(const T* __restrict__ x, int64_t l
         double t[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) t[r] = 0;
+        // (matrix row and mean in chunks of eight, all loads of a chunk requested before the first multiply, was measured late in round 5:
+        // 14.8 -> 22 us for the four-classifier launch.  Not kept.)
         for (int j = 0; j < d; ++j) {
             const double sj = S[j], mj = m[j];
 #pragma unroll
