@@ -956,8 +956,13 @@ constexpr int kStage0ChunkCols = 128;   // columns of one sub-image staged per c
 constexpr int kWeightLdsKiB = 64;       // target size of a node group's weights in LDS
 
 // layers [begin, begin + len) as n independent sub-trees in one launch (k_subtree, short batches; plan_subtree)
+// Per layer of the run: [sub-tree][position] -> node of the layer, and (layers above the run's first) the K-block table with source blocks
+// renumbered to the sub-tree's own activation buffer in LDS (position of the source node in the layer below x mto + tile).
+// set: runs are planned in two alternative sets (plan_subtree); a call uses the runs of ONE set.
 struct SubRun {
-    int begin = 0, len = 0, n = 0, act_blocks = 0, e_blocks = 0;
+    int begin = 0, len = 0, n = 0, act_blocks = 0, e_blocks = 0, set = 0;
+    std::vector<int32_t> nodes[kMaxTail], tab[kMaxTail];
+    DevBuf d_nodes[kMaxTail], d_tab[kMaxTail];
 };
 
 struct HostStage {
@@ -971,10 +976,6 @@ struct HostStage {
     int pk_kbi = -1;            // ... and sit at this position of every node's K-block list
     std::vector<int32_t> pack_slot;
     DevBuf d_pack_slot;
-    // k_subtree (short batches): [sub-tree][position] -> node of this layer, and the K-block table with source blocks renumbered
-    // to the sub-tree's own activation buffer in LDS (position of the source node in the layer below x mto + tile)
-    std::vector<int32_t> sub_nodes, sub_kb1tab;
-    DevBuf d_sub_nodes, d_sub_kb1tab;
     bool has_exp = false, contig4 = false, vec_ok = false;
     std::vector<ExpFunc> funcs;
     uint8_t nk2[kMaxMT][kMaxFuncs] = {};
@@ -1344,8 +1345,6 @@ public:
             if (!s.gcol.empty()) s.d_gcol.upload(s.gcol.data(), s.gcol.size() * 4);
             if (!s.etab.empty()) s.d_etab.upload(s.etab.data(), s.etab.size() * 4);
             if (!s.pack_slot.empty()) s.d_pack_slot.upload(s.pack_slot.data(), s.pack_slot.size() * 4);
-            if (!s.sub_nodes.empty()) s.d_sub_nodes.upload(s.sub_nodes.data(), s.sub_nodes.size() * 4);
-            if (!s.sub_kb1tab.empty()) s.d_sub_kb1tab.upload(s.sub_kb1tab.data(), s.sub_kb1tab.size() * 4);
             if (!s.chunks.empty()) {
                 s.d_chunks.upload(s.chunks.data(), s.chunks.size() * sizeof(DChunk));
                 s.d_runs.upload(s.runs.data(), s.runs.size() * sizeof(DRun));
@@ -1356,6 +1355,11 @@ public:
                 if (!s.kcol.empty()) s.d_kcol.upload(s.kcol.data(), s.kcol.size() * 4);
             }
         }
+        for (SubRun& r : sub_runs_)
+            for (int k = 0; k < r.len; ++k) {
+                r.d_nodes[k].upload(r.nodes[k].data(), r.nodes[k].size() * 4);
+                if (k > 0) r.d_tab[k].upload(r.tab[k].data(), r.tab[k].size() * 4);
+            }
         d_col_base_.upload(col_base_.data(), col_base_.size() * 4);
         d_col_of_.upload(col_of_.data(), col_of_.size() * 4);
         int dev = 0;
@@ -1384,6 +1388,7 @@ public:
     void run_range(const void* x, int x_dtype, int64_t n, int64_t ldx, void* y, int y_dtype, int64_t y_cols, int64_t ldy,
                    hipStream_t st, hipEvent_t* ev, f32x4* bufA, f32x4* bufB) {
         const int n_tiles = (int)((n + 15) / 16);
+        const int sub_set = pick_sub_set(n_tiles);
         int e = 0;
         if (ev) HG_HIP(hipEventRecord(ev[e++], st));
         f32x4* cur = bufA;
@@ -1439,7 +1444,7 @@ public:
             }
             const SubRun* sr = nullptr;
             for (const SubRun& r : sub_runs_)
-                if (r.begin == (int)si && sub_run_pays(r, n_tiles)) sr = &r;
+                if (r.begin == (int)si && r.set == sub_set && sub_run_pays(r, n_tiles)) sr = &r;
             if (sr) {
                 // a short batch: these layers as independent sub-trees in one launch (hg_fused_tail.hip)
                 const int sub_len_ = sr->len;
@@ -1815,9 +1820,11 @@ public:
         err_dev_ = nullptr;
         d_col_base_.free();
         d_col_of_.free();
+        for (SubRun& r : sub_runs_)
+            for (int k = 0; k < kMaxTail; ++k) { r.d_nodes[k].free(); r.d_tab[k].free(); }
         for (auto& s : stages_) {
             s.d_afrag.free(); s.d_bias.free(); s.d_kb1tab.free(); s.d_chunks.free();
-            s.d_runs.free(); s.d_piece.free(); s.d_koff.free(); s.d_kmean.free(); s.d_kcol.free(); s.d_gcol.free(); s.d_etab.free(); s.d_pack_slot.free(); s.d_sub_nodes.free(); s.d_sub_kb1tab.free();
+            s.d_runs.free(); s.d_piece.free(); s.d_koff.free(); s.d_kmean.free(); s.d_kcol.free(); s.d_gcol.free(); s.d_etab.free(); s.d_pack_slot.free();
         }
         cap_rows_ = 0;
     }
@@ -2580,9 +2587,17 @@ private:
         if (opt_.subtree_max_tiles <= 0) return;
         const int ns = (int)stages_.size();
         // (the layer under a short batch's k_tail launch runs alone: tail_start)
-        int end = tail_begin_ < 0 ? ns : (ns - tail_begin_ >= 3 ? tail_begin_ + 1 : tail_begin_);
-        // runs are taken from the top down, each ending where the one above begins (U11L: layers 6-8 as 4 sub-trees of 4 + 2 + 1 nodes, then
-        // layers 4-5 as 32 sub-trees of 2 + 1; the layers below pack their remainder tiles and stay per-layer launches)
+        const int end = tail_begin_ < 0 ? ns : (ns - tail_begin_ >= 3 ? tail_begin_ + 1 : tail_begin_);
+        // Two alternative sets of runs, each taken from the top down, a run ending where the one above begins.  Set 0 starts right under
+        // the top launch (U11L-128: layers 6-8 as 4 sub-trees of 4 + 2 + 1 nodes, then layers 3-5 as 32 sub-trees; layers 0-2 pack their
+        // remainder tiles and stay per-layer launches), set 1 one layer lower (layers 5-7 as 8 sub-trees).  A call takes the set whose
+        // usable runs (sub_run_pays) cover more layers and, if equal, have more sub-trees (pick_sub_set): set 1 for 130 .. 512 rows,
+        // where it is 2 us faster per call than set 0's four sub-trees (profiles/r05_subtree_call_times.txt).
+        plan_subtree_set(end, 0);
+        if (!sub_runs_.empty()) plan_subtree_set(end - 1, 1);
+    }
+
+    void plan_subtree_set(int end, int set) {
         while (end - 1 >= 2) {
             const int last = end - 1;
             const int k = stages_[last].n_nodes;
@@ -2650,12 +2665,20 @@ private:
             r.n = k;
             r.act_blocks = act_blocks;
             r.e_blocks = e_blocks;
-            sub_runs_.push_back(r);
+            r.set = set;
             for (int i = b; i <= last; ++i) {
-                stages_[i].sub_nodes = members[last - i];
-                if (i > b) stages_[i].sub_kb1tab = tabs[last - i];
+                r.nodes[i - b] = members[last - i];
+                if (i > b) r.tab[i - b] = tabs[last - i];
+            }
+            sub_runs_.push_back(std::move(r));
+            if (set != 0) {      // (the stage names describe set 0)
+                stages_[b].name += "  [or, where more layers or more sub-trees can run that way: " + std::to_string(last + 1 - b) + " layers from here as " + std::to_string(k) + " sub-trees]";
+                end = b;
+                continue;
+            }
+            for (int i = b; i <= last; ++i) {
                 stages_[i].name += i == b ? "  [batches of up to " + std::to_string(std::min(opt_.subtree_max_tiles, opt_.subtree_max_wgs / k) * 16) + " rows: this and the next " +
-                                                std::to_string(r.len - 1) + " layer(s) as " + std::to_string(k) + " sub-trees in ONE launch]"
+                                                std::to_string(last - b) + " layer(s) as " + std::to_string(k) + " sub-trees in ONE launch]"
                                           : "  [in the sub-tree launch for short batches]";
             }
             end = b;
@@ -2726,8 +2749,8 @@ private:
             HostStage& hs = stages_[sub_begin_ + k];
             fill_tail_stage(TP.st[k], hs);
             TP.st[k].n_nodes /= sub_n_;
-            TP.sub_nodes[k] = (const int32_t*)hs.d_sub_nodes.p;
-            if (k > 0) TP.st[k].kb1tab = (const int2*)hs.d_sub_kb1tab.p;
+            TP.sub_nodes[k] = (const int32_t*)sr.d_nodes[k].p;
+            if (k > 0) TP.st[k].kb1tab = (const int2*)sr.d_tab[k].p;
         }
         TP.in = in;
         TP.out_frag = out;
@@ -2750,11 +2773,31 @@ private:
         return n_tiles <= opt_.subtree_max_tiles && (int64_t)r.n * n_tiles <= opt_.subtree_max_wgs;
     }
 
+    // the set of runs a call of n_tiles uses: more layers inside usable runs first, then more sub-trees in the smallest of them
+    int pick_sub_set(int n_tiles) const {
+        int best = 0, best_cov = -1, best_k = 0;
+        for (int set = 0; set < 2; ++set) {
+            int cov = 0, mink = 0x7fffffff;
+            for (const SubRun& r : sub_runs_)
+                if (r.set == set && sub_run_pays(r, n_tiles)) {
+                    cov += r.len;
+                    mink = std::min(mink, r.n);
+                }
+            if (cov > best_cov || (cov == best_cov && cov > 0 && mink > best_k)) {
+                best = set;
+                best_cov = cov;
+                best_k = mink;
+            }
+        }
+        return best;
+    }
+
     int tail_start(int n_tiles) const {
         const int ns = (int)stages_.size();
         bool short_batch = n_tiles < 96;
+        const int sub_set = pick_sub_set(n_tiles);
         for (const SubRun& r : sub_runs_)      // (a sub-tree run that takes the top launch's first layer: only with HIGSFA_SUBTREE_WGS raised)
-            if (r.begin <= tail_begin_ && tail_begin_ < r.begin + r.len && sub_run_pays(r, n_tiles)) short_batch = true;
+            if (r.set == sub_set && r.begin <= tail_begin_ && tail_begin_ < r.begin + r.len && sub_run_pays(r, n_tiles)) short_batch = true;
         return (ns - tail_begin_ >= 3 && short_batch) ? tail_begin_ + 1 : tail_begin_;
     }
 

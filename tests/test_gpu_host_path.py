@@ -239,7 +239,8 @@ def test_subtree_launch_for_short_batches(native_lib, nets, monkeypatch, preset)
     hg_fused_tail.hip; HIGSFA_SUBTREE = largest batch in 16-row tiles, 0 = never).  Same products in the same order as the per-layer
     kernels: the same bits with the launches off, at their default and forced on for long batches (where the run under the top
     takes the top launch's first layer away from it), for ragged batches and for both output types; and the sub-trees the planner
-    found are the roots' own (the nodes a root reads are not consecutive in every layer)."""
+    found are the roots' own (the nodes a root reads are not consecutive in every layer).  Between 130 and 512 rows the default plan
+    uses its alternative set of runs (layers 5-7 as eight sub-trees): the batch sizes below cover both sets."""
     nodes = nets(preset)
     side = 128 if preset == "U11L-128" else 64
     x = synth.make_subimages(1300, side, dtype=np.uint8)
@@ -276,10 +277,10 @@ def test_subtree_launch_for_short_batches(native_lib, nets, monkeypatch, preset)
     b = Bench()
     assert np.array_equal(default.execute(x[:130], benchmark=b), base[:130])
     assert len(b.tasks) == default.info().n_stages
-    # (at 130 rows the run of four sub-trees is in use; the run of 32 only up to 128 rows: its layers are timed one by one here)
-    first = [i for i, t in enumerate(b.tasks) if "as 4 sub-trees in ONE launch" in t[0]]
-    assert len(first) == 1 and b.tasks[first[0]][1] > 0
-    assert b.tasks[first[0] + 1][1] < b.tasks[first[0]][1] and b.tasks[first[0] + 2][1] < b.tasks[first[0]][1]
+    # (at 130 rows one three-layer run is in use — of the alternative set, eight sub-trees, where the net has one: its time is carried by
+    # the first of its layers, the other two read the few microseconds between two event records)
+    assert all(t[1] >= 0 for t in b.tasks) and sum(t[1] for t in b.tasks) > 0
+    assert "layers from here as 8 sub-trees]" in default.describe()
     for f in (off, forced, default, f64):
         f.close()
 
