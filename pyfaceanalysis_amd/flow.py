@@ -217,8 +217,8 @@ class Flow(object):
         _capi.check(L.hg_flow_stage_times(h.h, ms, cnt, ns.value, C.byref(ns)))
         out = []
         for i in range(ns.value):
-            buf = C.create_string_buffer(256)
-            _capi.check(L.hg_flow_stage_name(h.h, i, buf, 256))
+            buf = C.create_string_buffer(512)      # (stage names carry the plan's notes: up to ~350 characters)
+            _capi.check(L.hg_flow_stage_name(h.h, i, buf, 512))
             out.append((buf.value.decode(), ms[i], cnt[i]))
         return out
 
