@@ -56,6 +56,8 @@ struct FusedOptions {
     int splitm_max_nodes = 4;     // experiments: HIGSFA_SPLITM_MAX
     int splitm_max_wgs = 512;     // HIGSFA_SPLITM_WGS: largest k_stage_splitm grid for layers of more than splitm_max_nodes nodes
     int shape_variant = 0;        // experiments: HIGSFA_SHAPES
+    int stage_w = 0, stage_t = 0; // experiments: HIGSFA_STAGE_SHAPE=waves,tiles for every k_stage launch
+    int stage_parts = 0;          // experiments: HIGSFA_STAGE_PARTS=tile parts of every k_stage launch
     static FusedOptions from_env() {
         FusedOptions o;
         o.no_rem4 = getenv("HIGSFA_NO_REM4") != nullptr;
@@ -74,6 +76,8 @@ struct FusedOptions {
         if (const char* e = getenv("HIGSFA_SPLITM_MAX")) o.splitm_max_nodes = atoi(e);
         if (const char* e = getenv("HIGSFA_SPLITM_WGS")) o.splitm_max_wgs = atoi(e);
         if (const char* e = getenv("HIGSFA_SHAPES")) o.shape_variant = atoi(e);
+        if (const char* e = getenv("HIGSFA_STAGE_SHAPE")) sscanf(e, "%d,%d", &o.stage_w, &o.stage_t);
+        if (const char* e = getenv("HIGSFA_STAGE_PARTS")) o.stage_parts = atoi(e);
         if (const char* e = getenv("HIGSFA_SUBTREE")) o.subtree_max_tiles = std::max(0, atoi(e));
         if (const char* e = getenv("HIGSFA_SUBTREE_WGS")) o.subtree_max_wgs = std::max(0, atoi(e));
         if (const char* e = getenv("HIGSFA_TAIL")) o.tail_max = std::max(0, std::min(atoi(e), kMaxTail));
@@ -1719,6 +1723,10 @@ public:
                         break;
                     }
                 }
+                if (opt_.stage_w > 0) {      // experiments (HIGSFA_STAGE_SHAPE=waves,tiles)
+                    nw = opt_.stage_w;
+                    T = opt_.stage_t;
+                }
                 while (nw * T > std::max(n_tiles, 1) && nw > 1) nw >>= 1;
                 const int tile_groups = (n_tiles + nw * T - 1) / (nw * T);
                 // persistent sweep: each workgroup copies its node group's weights once and walks
@@ -1744,6 +1752,7 @@ public:
                         tile_parts = pp;
                     }
                 }
+                if (opt_.stage_parts > 0) tile_parts = std::min(opt_.stage_parts, tile_groups);      // experiments (HIGSFA_STAGE_PARTS)
                 P.nodes_per_group = npg;
                 P.nodes_per_wg = npg;
                 P.n_chunks = n_groups;
