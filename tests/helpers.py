@@ -294,3 +294,45 @@ def remainder_net(seed=0):
     sb2 = N.Rectangular2dSwitchboard((4, 8), (1, 2), (1, 2), 12)       # 16 nodes of 24 inputs
     sb3 = N.Rectangular2dSwitchboard((4, 4), (2, 1), (2, 1), 18)       # 8 nodes of 36 inputs
     return [sb0, layer(64, 16, 10, 9), sb1, layer(32, 18, 14, 12), sb2, layer(16, 24, 19, 18), sb3, layer(8, 36, 35, 34)]
+
+
+def subtree_fuzz_net(seed):
+    """Deep hierarchies WITHOUT overlap (every node read by exactly one node of the next layer), random merge shapes (2x1, 1x2, 2x2,
+    3x1), node widths and expansions: the upper layers fall into independent sub-trees, which the fused plan may run as one launch
+    per run of layers for short batches (k_subtree, plan_subtree).  Grids are chosen so that several layers have >= 4 nodes."""
+    rng = np.random.default_rng(7000 + seed)
+    w, h = [(16, 8), (8, 8), (12, 6), (16, 16), (8, 4), (6, 6)][int(rng.integers(0, 6))]
+    pool = [N.identity, N.unsigned_08expo, N.signed_08expo, N.unsigned_expo(float(rng.uniform(0.5, 1.5)))]
+    fx0, fy0 = (int(v) for v in rng.choice([2, 3, 4], 2))
+    sb = N.Rectangular2dSwitchboard((w * fx0, h * fy0), (fx0, fy0), (fx0, fy0), 1)
+    flow, c = [], 1
+    first = True
+    while True:
+        if first:
+            first = False
+        else:
+            opts = [(fx, fy) for fx, fy in ((2, 1), (1, 2), (2, 2), (3, 1), (1, 3)) if w % fx == 0 and h % fy == 0]
+            if not opts:
+                break
+            fx, fy = opts[int(rng.integers(0, len(opts)))]
+            sb = N.Rectangular2dSwitchboard((w, h), (fx, fy), (fx, fy), c)
+        n_nodes, d_in = sb.output_channels, sb.out_channel_dim
+        p0 = int(rng.integers(3, min(d_in, 48) + 1))
+        s0 = int(rng.integers(4, 61))
+        linear = rng.random() < 0.15
+        nf = int(rng.integers(1, 3))
+        funcs = [pool[int(i)] for i in rng.choice(len(pool), nf, replace=False)]
+
+        def make():
+            if linear:
+                return N.FlowNode([rand_pca(rng, d_in, p0), rand_sfa(rng, p0, s0)])
+            ex = N.GeneralExpansionNode(funcs, p0)
+            return N.FlowNode([rand_pca(rng, d_in, p0), ex, rand_sfa(rng, ex.output_dim, s0)])
+
+        layer = N.Layer([make() for _ in range(n_nodes)])
+        flow += [sb, layer]
+        w, h = sb.out_channels_xy
+        c = layer.output_dim // n_nodes
+        if w * h == 1:
+            break
+    return flow

@@ -76,10 +76,29 @@ def test_u11l_128_plan(native_lib, nets):
     assert inf.flops_per_row == 11017088 and inf.padded_flops_per_row == 12158976
     assert "issued: 24576 x 16x16x4 + 0 x 4x4x1" in desc and "issued: 9216 x 16x16x4 + 9216 x 4x4x1" in desc
     assert inf.input_dim == 16384 and inf.output_dim == 60 and inf.n_top_nodes == 22
+    # short batches: runs of layers that fall into independent sub-trees, one launch each (round 5; planned on the host: k_subtree) —
+    # layers 6-8 under four roots, layers 3-5 under 32, and the alternative set one layer lower (5-7 under eight)
+    assert "this and the next 2 layer(s) as 4 sub-trees in ONE launch" in desc and "this and the next 2 layer(s) as 32 sub-trees in ONE launch" in desc
+    assert "3 layers from here as 8 sub-trees]" in desc and desc.count("[in the sub-tree launch for short batches]") == 4
     # iGSFA variant: three ordinary (folded) layers, then wide nodes on the node kernel in its folded form
     inf, desc = Flow(nets("U11L-128", node_kind="igsfa")).host_plan()
     assert inf.plan_kind == _capi.HG_PLAN_FUSED and inf.n_stages == 12
     assert desc.count("fused iGSFA stage (folded to one GEMM)") == 8 and "fused gather" not in desc
+
+
+def test_subtree_runs_are_planned_where_layers_split(native_lib):
+    """plan_subtree on the host: hierarchies without overlap get runs of sub-trees (4 ... 32 roots, merges of 2, 3, 4 children); a
+    net whose receptive fields overlap gets none."""
+    planned = 0
+    for seed in range(16):
+        _, desc = Flow(helpers.subtree_fuzz_net(seed)).host_plan()
+        for ln in desc.splitlines():
+            if "sub-trees in ONE launch" in ln:
+                assert int(ln.split(" sub-trees in ONE launch")[0].split(" as ")[-1]) >= 4
+        planned += "sub-trees in ONE launch" in desc
+    assert planned >= 12
+    _, desc = Flow(helpers.overlapping_net(5)).host_plan()
+    assert "sub-trees in ONE launch" not in desc
 
 
 def test_malformed_blobs_are_rejected(native_lib):

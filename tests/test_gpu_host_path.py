@@ -285,6 +285,31 @@ def test_subtree_launch_for_short_batches(native_lib, nets, monkeypatch, preset)
         f.close()
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_subtree_launch_on_random_tree_hierarchies(native_lib, monkeypatch, seed):
+    """Random hierarchies without overlap (helpers.subtree_fuzz_net: merges of 2, 3 and 4 children, 4 ... 32 roots, node widths of one
+    to four tiles, one or two expansion functions or none): where the planner finds runs of sub-trees, short batches through them
+    give the bits of per-layer launches (HIGSFA_SUBTREE=0) and agree with the oracle."""
+    nodes = helpers.subtree_fuzz_net(seed)
+    rng = np.random.default_rng(seed)
+    x = (rng.normal(size=(150, nodes[0].input_dim)) * 1.5).astype(np.float32)
+    monkeypatch.setenv("HIGSFA_SUBTREE", "0")
+    off = Flow(nodes, output_dtype=np.float32)
+    assert "sub-trees in ONE launch" not in off.describe()
+    monkeypatch.delenv("HIGSFA_SUBTREE")
+    on = Flow(nodes, output_dtype=np.float32)
+    planned = "sub-trees in ONE launch" in on.describe()
+    base = off.execute(x)
+    assert rel_err(base[:24], oracle.execute_flow(nodes, x[:24])) <= TOL
+    for n in (1, 16, 20, 75, 150, 130):
+        assert np.array_equal(on.execute(x[:n]), base[:n]), (seed, n, planned)
+    k = max(1, nodes[-1].output_dim // 2)
+    assert np.array_equal(on.execute(x[:33], n_cols=k), base[:33, :k])
+    print("seed %d: %s" % (seed, [ln.split("[batches of up to")[1][:64] for ln in on.describe().splitlines() if "sub-trees in ONE launch" in ln]))
+    off.close()
+    on.close()
+
+
 def test_subtree_launch_is_planned_only_where_the_layers_split(native_lib, nets):
     """Overlapping receptive fields (a node of the layer below feeds two nodes above) leave no independent sub-trees: no plan."""
     for nodes in (helpers.overlapping_net(5), helpers.linear_net(3), nets("T5L-16")):
