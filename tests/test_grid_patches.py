@@ -85,7 +85,9 @@ def test_rotated_patch_extraction_matches_pil(native_lib):
     angs[:len(special)] = special
     angs[-4:] = [33.0, -12.0, 180.0, 181.0]
     p = Patcher()
-    for size in ((64, 64), (37, 21)):
+    # ((128, 128): the pipelines' size; (16, 7), (32, 10): rows of sixteen pixels whose table rows are not all 16-byte aligned — the sixteen
+    # table entries then come as scalar loads; (37, 21): the four-pixels-per-thread path)
+    for size in ((64, 64), (37, 21), (128, 128), (16, 7), (32, 10)):
         ref = _pil_rotated_windows(frame, boxes, angs, size)
         got = p.extract(frame, boxes, size, dtype=np.uint8, delta_angs=angs)
         bad = np.nonzero((got != ref).any(axis=1))[0]
