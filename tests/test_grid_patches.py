@@ -52,6 +52,15 @@ def test_patch_extraction_matches_pil(native_lib):
             assert got.dtype == dt and got.shape == (len(boxes), size[0] * size[1])
             assert np.array_equal(got.astype(np.int64), ref.astype(np.int64))
     assert p.extract(frame, np.zeros((0, 4)), (64, 64)).shape == (0, 4096)
+    # a frame's first stage: all 1738 windows of the 1080p grid at 128 x 128 (whole windows per workgroup from 1024 boxes on; fewer boxes
+    # above took row chunks), and a handful of boxes (one row pass per workgroup)
+    boxes = np.concatenate([b for _, b in grid.frame_boxes(1000, 562, 0.1, subimage_size=(128, 128))])
+    assert len(boxes) == 1738
+    got = p.extract(frame, boxes, (128, 128), dtype=np.uint8)
+    for i in list(range(0, 1738, 13)) + [1737]:
+        assert np.array_equal(got[i], np.asarray(im.transform((128, 128), Image.EXTENT, tuple(boxes[i]), Image.NEAREST)).reshape(-1)), i
+    few = p.extract(frame, boxes[[0, 900, 1737]], (128, 128), dtype=np.uint8)
+    assert np.array_equal(few, got[[0, 900, 1737]])
     p.close()
 
 
