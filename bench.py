@@ -173,12 +173,19 @@ def _frame_leg(flow, dev, reps, flow_factory):
     # five batches of `reps` frames, the median batch reported (one host hiccup of a few ms in a single 0.13 s batch moved the
     # figure by 2-3 %: round 5 saw 1.25 ... 1.30 ms from one build on one box); all five are in the line
     batches = []
+    first_out = dc.detect_frame(frame, smallest_face=0.1)
+    frames_identical = True      # every timed frame's survivors (boxes, angles, confidences, counts per stage) against the first frame's, bit for bit
     for _ in range(5):
+        outs = []
         t0 = time.perf_counter()
         for _ in range(reps):
-            out = dc.detect_frame(frame, smallest_face=0.1)
+            outs.append(dc.detect_frame(frame, smallest_face=0.1))
         torch.cuda.synchronize(dev)
         batches.append((time.perf_counter() - t0) / reps)
+        out = outs[-1]
+        for o in outs:      # (compared outside the timed region)
+            frames_identical = frames_identical and list(o["counts"]) == list(first_out["counts"]) and all(
+                np.array_equal(o[k], first_out[k]) for k in ("coords", "angles", "orig_index", "confidence"))
     batches.sort()
     per_frame = batches[2]
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -229,7 +236,7 @@ def _frame_leg(flow, dev, reps, flow_factory):
             c2.close()
             for f_ in f2:
                 f_.close()
-    res = {"frames_per_s": 1.0 / per_frame, "ms_per_frame": per_frame * 1e3, "ms_per_frame_batches": [round(b * 1e3, 4) for b in batches], "frame": "1920x1080 synthetic, prescaled 1000x562, smallest_face 0.1",
+    res = {"frames_per_s": 1.0 / per_frame, "ms_per_frame": per_frame * 1e3, "ms_per_frame_batches": [round(b * 1e3, 4) for b in batches], "frames_identical": bool(frames_identical), "frame": "1920x1080 synthetic, prescaled 1000x562, smallest_face 0.1",
            "levels": int(len(np.unique(level[:, 2]))), "windows": n0, "stages": len(stages), "rows_executed": int(out["rows_executed"]),
            "survivors_per_stage": [int(c) for c in out["counts"]], "detections": int(out["counts"][-1]),
            "detections_per_s": float(out["counts"][-1]) / per_frame,
