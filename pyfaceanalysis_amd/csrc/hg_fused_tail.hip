@@ -236,12 +236,14 @@ __global__ void __launch_bounds__(WAVES * 64) k_tail(TailParams P) {
     }
 }
 
-// k_subtree: two or three layers BELOW the top as one launch for short batches.  Where the receptive fields tile the layer
-// below without overlap (every node of a layer is read by exactly one node of the next: all through the upper half of the preset
-// hierarchies), the fused layers fall into n_sub independent sub-trees (the planner lists each one's nodes: plan_subtree); a workgroup takes one sub-tree for one batch tile the way k_tail
-// takes the whole top, and writes the sub-tree's root tiles back in fragment order.  A short batch (one 1080p frame's later
-// cascade stages: 18 .. 348 windows) leaves every per-layer launch at its floor of 9-12 us; this replaces three of them.
-// Consecutive workgroups are the sub-trees of one tile, so with 8 sub-trees each XCD's L2 holds the weights of one.
+// k_subtree: two or three layers BELOW the top as one launch for short batches.  Where the receptive fields tile the layer below
+// without overlap (every node of a layer is read by exactly one node of the next: all through the upper half of the preset
+// hierarchies), a run of layers falls into n_sub independent sub-trees (the planner lists each one's nodes: plan_subtree in
+// hg_fused.hip); a workgroup takes one sub-tree for one batch tile the way k_tail takes the whole top, and writes the sub-tree's
+// root tiles back in fragment order.  A short batch (one 1080p frame's later cascade stages: 18 .. 348 windows) leaves every
+// per-layer launch at its floor of 9-12 us; a run replaces three of them.  Consecutive workgroups are the sub-trees of one tile.
+// What it costs: a workgroup pulls its sub-tree's weights (up to 784 KiB for 4 + 2 + 1 nodes) through ONE compute unit's L1, so a
+// run is used only while all its workgroups are resident at once (FusedExec::sub_run_pays; profiles/r05_tail_stamps.txt).
 template <int T, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) k_subtree(TailParams P) {
     extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
