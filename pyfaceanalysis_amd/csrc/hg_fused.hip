@@ -58,6 +58,7 @@ struct FusedOptions {
     int shape_variant = 0;        // experiments: HIGSFA_SHAPES
     int stage_w = 0, stage_t = 0; // experiments: HIGSFA_STAGE_SHAPE=waves,tiles for every k_stage launch
     int stage_parts = 0;          // experiments: HIGSFA_STAGE_PARTS=tile parts of every k_stage launch
+    int stage_only = -1;          // experiments: HIGSFA_STAGE_ONLY=<stage>: the two knobs above for that stage only
     static FusedOptions from_env() {
         FusedOptions o;
         o.no_rem4 = getenv("HIGSFA_NO_REM4") != nullptr;
@@ -78,6 +79,7 @@ struct FusedOptions {
         if (const char* e = getenv("HIGSFA_SHAPES")) o.shape_variant = atoi(e);
         if (const char* e = getenv("HIGSFA_STAGE_SHAPE")) sscanf(e, "%d,%d", &o.stage_w, &o.stage_t);
         if (const char* e = getenv("HIGSFA_STAGE_PARTS")) o.stage_parts = atoi(e);
+        if (const char* e = getenv("HIGSFA_STAGE_ONLY")) o.stage_only = atoi(e);
         if (const char* e = getenv("HIGSFA_SUBTREE")) o.subtree_max_tiles = std::max(0, atoi(e));
         if (const char* e = getenv("HIGSFA_SUBTREE_WGS")) o.subtree_max_wgs = std::max(0, atoi(e));
         if (const char* e = getenv("HIGSFA_TAIL")) o.tail_max = std::max(0, std::min(atoi(e), kMaxTail));
@@ -1723,7 +1725,7 @@ public:
                         break;
                     }
                 }
-                if (opt_.stage_w > 0) {      // experiments (HIGSFA_STAGE_SHAPE=waves,tiles)
+                if (opt_.stage_w > 0 && (opt_.stage_only < 0 || opt_.stage_only == (int)si)) {      // experiments (HIGSFA_STAGE_SHAPE=waves,tiles; HIGSFA_STAGE_ONLY=<stage>)
                     nw = opt_.stage_w;
                     T = opt_.stage_t;
                 }
@@ -1752,7 +1754,7 @@ public:
                         tile_parts = pp;
                     }
                 }
-                if (opt_.stage_parts > 0) tile_parts = std::min(opt_.stage_parts, tile_groups);      // experiments (HIGSFA_STAGE_PARTS)
+                if (opt_.stage_parts > 0 && (opt_.stage_only < 0 || opt_.stage_only == (int)si)) tile_parts = std::min(opt_.stage_parts, tile_groups);      // experiments (HIGSFA_STAGE_PARTS)
                 P.nodes_per_group = npg;
                 P.nodes_per_wg = npg;
                 P.n_chunks = n_groups;
